@@ -1,0 +1,155 @@
+/*
+ * met2_hip.h -- C ABI of libmet2_hip.so, the MI355X (gfx950) implementation of the
+ * per-voxel regularised-NNLS T2-spectrum path of ejcanalesr/multicomponent-T2-toolbox.
+ *
+ * The reference has no FFI layer: its boundary is Python function calls inside one
+ * process.  Each entry point below names the reference function (or
+ * driver code) it replaces; INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - all arithmetic is IEEE fp64;
+ *   - "host" pointers are ordinary process memory (small parameter arrays);
+ *     "device" pointers are HIP device memory on the plan's device (bulk voxel arrays);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous with respect to the host unless stated otherwise;
+ *   - every function returns 0 on success, a negative MET2_E_* code otherwise;
+ *     met2_last_error() gives the message of the calling thread's last failure;
+ *   - a plan may be used from one host thread at a time; different plans (e.g. one per
+ *     device) may be used concurrently.
+ */
+#ifndef MET2_HIP_H
+#define MET2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MET2_ABI_VERSION 1
+
+/* reg_method of motor/motor_recon_met2_real_data.py:134-150 */
+enum met2_method {
+    MET2_NNLS = 0,      /* algorithms.py:55  nnls                      reg_param = 0      */
+    MET2_T2SPARC = 1,   /* algorithms.py:262 nnls_tik, lambda = 1.8    reg_param = 1.8    */
+    MET2_X2 = 2,        /* algorithms.py:211 nnls_x2, factor = 1.02    reg_param = k_est  */
+    MET2_LCURVE = 3,    /* algorithms.py:88  nnls_lcurve_wrapper + nnls_tik, reg_param = lambda */
+    MET2_GCV = 4,       /* algorithms.py:276 nnls_gcv                  reg_param = lambda */
+    MET2_BAYESREG = 5   /* bayesian_interpolation.py:84 BayesReg_nnls  reg_param = lambda */
+};
+
+/* reg_matrix of motor:254-273 */
+enum met2_penalty { MET2_PEN_I = 0, MET2_PEN_L1 = 1, MET2_PEN_L2 = 2, MET2_PEN_INVT2 = 3 };
+
+/* per-voxel status bits written by met2_fit */
+enum met2_status {
+    MET2_ST_FITTED = 1,        /* passed the gates of motor:124,131 and was solved                 */
+    MET2_ST_ITMAX = 2,         /* some inner NNLS hit the 3n iteration cap (reference ignores it)  */
+    MET2_ST_NONFINITE = 4,     /* NaN/Inf in the voxel's echoes: outputs zero (reference: ValueError) */
+    MET2_ST_CHOLFAIL = 8,      /* BayesReg: Cholesky of beta(B + lambda K) failed (reference: LinAlgError) */
+    MET2_ST_BRENT_MAXFUN = 16, /* lambda search stopped on maxfun                                  */
+    MET2_ST_KOVERFLOW = 32     /* internal passive-set capacity exceeded (never with default build) */
+};
+
+enum met2_error {
+    MET2_OK = 0,
+    MET2_E_INVALID = -1,       /* bad argument (shape, NULL, enum)        */
+    MET2_E_UNSUPPORTED = -2,   /* shape/penalty outside the built kernels */
+    MET2_E_HIP = -3,           /* a HIP runtime call failed               */
+    MET2_E_NODEVICE = -4,      /* no gfx950 device visible                */
+    MET2_E_STATE = -5          /* plan not fully configured for this call */
+};
+
+typedef struct met2_plan met2_plan;
+
+/* Constants the reference buries in its driver; defaults = reference values. */
+typedef struct met2_options {
+    int32_t struct_size;      /* sizeof(met2_options), for ABI growth                      */
+    int32_t device;           /* HIP device ordinal                                        */
+    double x2_factor;         /* motor:141            1.02                                 */
+    double t2sparc_lambda;    /* motor:138            1.8                                  */
+    double brent_xtol;        /* algorithms.py:219    1e-5                                 */
+    int32_t brent_maxfun;     /* 0 = reference value: 300 (X2, GCV), 200 (BayesReg)        */
+    int32_t reserved0;
+    double t2_myelin_cut;     /* motor:216 (myelin_T2 CLI flag)   40.0                     */
+    double t2_ie_cut;         /* motor:217            200.0                                */
+} met2_options;
+
+void met2_default_options(met2_options *opt);
+
+int met2_abi_version(void);
+int met2_device_count(void);
+const char *met2_last_error(void);
+
+/* ---- plan: the shared nTE x nT2 x nFA problem (dictionary, Gram matrices, penalty) ---- */
+int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, const met2_options *opt);
+int met2_plan_destroy(met2_plan *plan);
+
+/* epg/epg.py:155 create_Dic_3D -- EPG dictionary built on the device, one wave per
+ * (T2, flip angle).  T2s/T1s [n_t2], alpha_deg [n_fa] are host arrays.  Also forms the
+ * per-flip-angle Gram matrices D^T D used by the solver. */
+int met2_plan_build_dictionary_epg(met2_plan *plan, const double *T2s, const double *T1s, double tau,
+                                   const double *alpha_deg, double TR, void *stream);
+
+/* Dictionary handed in by the caller, reference layout Dic_3D[n_te][n_t2][n_fa] (host).
+ * Replaces the `Dic_3D` argument of fitting_slice_T2 (motor:113). */
+int met2_plan_set_dictionary(met2_plan *plan, const double *dic3d_host);
+
+/* Copies the dictionary back in the reference layout [n_te][n_t2][n_fa] (host, blocking). */
+int met2_plan_get_dictionary(met2_plan *plan, double *dic3d_host);
+
+/* motor:86 create_Laplacian_matrix / motor:263 InvT2.  T2s (host, [n_t2]) is needed for
+ * InvT2 only.  The dense form takes any `Laplac` [n_t2][n_t2] (host) whose L^T L has
+ * bandwidth <= 2 (true for I, L1, L2, InvT2); wider ones return MET2_E_UNSUPPORTED. */
+int met2_plan_set_penalty(met2_plan *plan, int32_t which, const double *T2s);
+int met2_plan_set_penalty_dense(met2_plan *plan, const double *laplac_host);
+int met2_plan_get_penalty(met2_plan *plan, double *laplac_host);
+
+/* motor:248-251 lambda_reg (host, [n]); default = the reference's 50-point grid */
+int met2_plan_set_lambda_grid(met2_plan *plan, const double *lambda_reg, int32_t n);
+
+/* motor:215-224 T2 grid for the metrics windows (host, [n_t2]); set automatically by
+ * met2_plan_build_dictionary_epg */
+int met2_plan_set_t2_grid(met2_plan *plan, const double *T2s);
+
+/* ---- hot path ------------------------------------------------------------------------
+ * motor:113 fitting_slice_T2 over a flat voxel list, fused with the step-4 metrics of
+ * motor:443-472.  All array arguments are DEVICE pointers:
+ *   data     [nvox][n_te]  echoes (un-normalised, as the driver passes them)
+ *   fa_index [nvox]        float64 index into the dictionary's FA axis (motor:127), NULL = 0
+ *   mask     [nvox]        uint8, voxel is fitted iff mask != 0 (motor:124), NULL = all ones
+ *   fsol     [nvox][n_t2]  out: x * km                       (motor:154)
+ *   sig      [nvox][n_te]  out: Kernel @ x * km              (motor:155), may be NULL
+ *   reg      [nvox]        out: reg_param                    (motor:153)
+ *   maps     [6][nvox]     out: MWF, IEWF, FWF, T2_M, T2_IE, TWC (motor:455-468), may be NULL
+ *   status   [nvox]        out: met2_status bits, may be NULL
+ * Gated-out voxels get zeros (motor:115-117) and, if mask != 0, the all-zero-spectrum
+ * metrics of motor:448-468. */
+int met2_fit(met2_plan *plan, int32_t method, int64_t nvox, const double *data, const double *fa_index,
+             const uint8_t *mask, double *fsol, double *sig, double *reg, double *maps, int32_t *status,
+             void *stream);
+
+/* flip_angle_algorithms/fa_estimation.py:74-111 (brute force over the plan's FA axis).
+ * DEVICE pointers: data [nvox][n_te] (un-normalised), mask [nvox] (NULL = ones);
+ * out fa_index [nvox] float64 (0 where gated out), km [nvox] = sum(f) at the best FA
+ * (may be NULL), resid [nvox][n_fa] NNLS residual norms (may be NULL). */
+int met2_fa_bruteforce(met2_plan *plan, int64_t nvox, const double *data, const uint8_t *mask,
+                       double *fa_index, double *km, double *resid, void *stream);
+
+/* motor:443-472 alone (fsol already on the device). */
+int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps,
+                 void *stream);
+
+/* Duration in ms of the solver kernel of the most recent met2_fit / met2_fa_bruteforce on
+ * this plan, measured with HIP events on the launch stream (blocks until it finished). */
+int met2_plan_last_kernel_ms(met2_plan *plan, double *ms);
+
+/* Launch geometry of the solver kernel (for reports): workgroups, threads per workgroup,
+ * dynamic LDS bytes per workgroup. */
+int met2_plan_launch_info(met2_plan *plan, int32_t method, int32_t *grid, int32_t *block, int32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MET2_HIP_H */
