@@ -1,0 +1,923 @@
+// met2_hip.hip -- gfx950 kernels and the C ABI of include/met2_hip.h.
+//
+// Kernels
+//   epg_dictionary_kernel   epg/epg.py:47-162      one wavefront per (T2, flip angle); the EPG
+//                                                  coherence orders live on the lanes, the
+//                                                  shift operator is a lane shuffle
+//   gram_kernel             B_fa = D_fa^T D_fa     (shared design-matrix Gram, once per plan)
+//   classify/scan/scatter   gates of motor:124,131 + counting sort of voxels by FA index so
+//                           that a workgroup stages one flip angle's D and B in LDS
+//   fit_kernel<METHOD>      motor:113-162 + motor:443-472: one voxel per wavefront, persistent
+//                           workgroups pulling FA-homogeneous chunks from an atomic queue
+//   finalize_unfitted       zeros / all-zero-spectrum metrics for gated-out voxels
+//   metrics_kernel          motor:443-472 standalone
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/met2_hip.h"
+#include "nnls_wave.hpp"
+
+using namespace met2;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(MET2_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// EPG dictionary  (epg/epg.py:64-153).  Lane k holds order k: Fp = F_k (lane 0: F_0),
+// Fm = F_-k, Z = Z_k.  One inter-echo period = P T P, P = shift then relax over tau/2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void epg_dictionary_kernel(int nte, int nt2, int nfa, const double *__restrict__ T2s,
+                                                             const double *__restrict__ T1s, double tau,
+                                                             const double *__restrict__ alpha_deg, double TR,
+                                                             double *__restrict__ D /* [nfa][nte][nt2] */)
+{
+    const int lane = lane_id();
+    const int gw = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (gw >= nfa * nt2) return;
+    const int fa = gw / nt2, j = gw - fa * nt2;
+    const double rad = M_PI / 180.0;
+    const double alpha = alpha_deg[fa] * rad, aexc = alpha_deg[fa] / 2.0 * rad;
+    const double th = tau / 2.0;
+    const double R2 = 1.0 / T2s[j], R1 = 1.0 / T1s[j];
+    const double E2 = exp(-th * R2), E1 = exp(-th * R1);
+    const double ca2 = cos(alpha / 2.0), sa2 = sin(alpha / 2.0);
+    const double c2 = ca2 * ca2, s2 = sa2 * sa2, sa = sin(alpha), ca = cos(alpha);
+    const double scale = 1.0 - exp(-TR / T1s[j]);
+    const int n = nte;
+    double Fp = (lane == 0) ? sin(aexc) : 0.0;
+    double Fm = (lane == 1) ? cos(aexc) : 0.0;
+    double Z = 0.0;
+    for (int e = 0; e < nte; ++e) {
+        for (int half = 0; half < 2; ++half) {
+            double up = gather(Fp, (lane + 63) & 63);     // F_{k-1}
+            double dn = gather(Fm, (lane + 1) & 63);      // F_-(k+1)
+            dn = (lane < n) ? dn : 0.0;                   // F_-n <- 0
+            Fp = (lane == 0) ? dn : up;                   // F_0 <- F_-1 ; F_k <- F_{k-1}
+            Fm = (lane == 0) ? 0.0 : dn;
+            Fp *= E2; Fm *= E2; Z *= E1;
+            if (lane > n) { Fp = 0.0; Fm = 0.0; Z = 0.0; }
+            if (half == 0 && lane >= 1) {
+                double a = Fp, b = Fm, z = Z;
+                Fp = c2 * a + s2 * b + sa * z;
+                Fm = s2 * a + c2 * b - sa * z;
+                Z = -0.5 * sa * a + 0.5 * sa * b + ca * z;
+            }
+        }
+        if (lane == 0) D[((size_t)fa * nte + e) * nt2 + j] = Fp * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_kernel(int nte, int nt2, const double *__restrict__ D, double *__restrict__ B)
+{
+    const double *Df = D + (size_t)blockIdx.x * nte * nt2;
+    double *Bf = B + (size_t)blockIdx.x * nt2 * nt2;
+    for (int idx = threadIdx.x; idx < nt2 * nt2; idx += blockDim.x) {
+        int a = idx / nt2, b = idx - a * nt2;
+        double t = 0.0;
+        for (int e = 0; e < nte; ++e) t = fma(Df[e * nt2 + a], Df[e * nt2 + b], t);
+        Bf[idx] = t;
+    }
+}
+
+// reference layout [te][t2][fa]  <->  device layout [fa][te][t2]
+__global__ void relayout_kernel(int nte, int nt2, int nfa, const double *__restrict__ src, double *__restrict__ dst, int to_device)
+{
+    size_t total = (size_t)nte * nt2 * nfa;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t f = i / ((size_t)nte * nt2), r = i - f * nte * nt2;     // i indexes [fa][te][t2]
+        size_t ref = r * nfa + f;
+        if (to_device) dst[i] = src[ref]; else dst[ref] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// voxel classification and counting sort by FA index
+// ------------------------------------------------------------------------------------------
+struct SortBufs {
+    int *key;          // [nvox]  fa index, or -1 if not fitted
+    int *perm;         // [nvox]  fitted voxels ordered by fa
+    int *hist;         // [nfa]
+    int *cursor;       // [nfa]
+    int *bucket_start; // [nfa+1]
+    int *chunk_start;  // [nfa+1]
+    int *queue;        // [1]
+    int *err;          // [1]  bit0: FA index out of range
+};
+
+__global__ __launch_bounds__(256) void classify_kernel(int64_t nvox, int nte, int nfa, const double *__restrict__ data,
+                                                       const double *__restrict__ fa_index, const uint8_t *__restrict__ mask,
+                                                       int require_first_echo, SortBufs sb, int32_t *__restrict__ status)
+{
+    const int lane = lane_id();
+    int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int key = -1, st = 0;
+    if (v < nvox) {
+        const double *M = data + (size_t)v * nte;
+        double sum = 0.0; bool finite = true;
+        for (int e = 0; e < nte; ++e) { double t = M[e]; sum += t; finite = finite && isfinite(t); }
+        bool mk = mask ? (mask[v] != 0) : true;
+        if (!finite) st = MET2_ST_NONFINITE;
+        else if (mk && sum > 0.0 && (!require_first_echo || M[0] > 0.0)) {
+            int fi = fa_index ? (int)fa_index[v] : 0;
+            if (fi < 0 || fi >= nfa) atomicOr(sb.err, 1);
+            else { key = fi; st = MET2_ST_FITTED; }
+        }
+        sb.key[v] = key;
+        if (status) status[v] = st;
+    }
+    // wave-aggregated histogram
+    u64 todo = ballot(key >= 0);
+    while (todo) {
+        int leader = first_lane(todo);
+        int k0 = bcast_i(key, leader);
+        u64 same = ballot(key == k0) & todo;
+        if (lane == leader) atomicAdd(&sb.hist[k0], __popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void scan_kernel(int nfa, int chunk, SortBufs sb)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0, cacc = 0;
+        for (int f = 0; f < nfa; ++f) {
+            sb.bucket_start[f] = acc; sb.chunk_start[f] = cacc; sb.cursor[f] = 0;
+            int c = sb.hist[f];
+            acc += c; cacc += (c + chunk - 1) / chunk;
+        }
+        sb.bucket_start[nfa] = acc; sb.chunk_start[nfa] = cacc;
+        sb.queue[0] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(int64_t nvox, SortBufs sb)
+{
+    const int lane = lane_id();
+    int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int key = (v < nvox) ? sb.key[v] : -1;
+    u64 todo = ballot(key >= 0);
+    while (todo) {
+        int leader = first_lane(todo);
+        int k0 = bcast_i(key, leader);
+        u64 same = ballot(key == k0) & todo;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&sb.cursor[k0], __popcll(same));
+        base = bcast_i(base, leader);
+        if (key == k0) {
+            int rank = __popcll(same & ((1ull << lane) - 1ull));
+            sb.perm[sb.bucket_start[k0] + base + rank] = (int)v;
+        }
+        todo &= ~same;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fit kernel
+// ------------------------------------------------------------------------------------------
+struct FitArgs {
+    int n, m, nfa, np, kmax, waves, chunk;
+    int method, nlam, maxfun;
+    double x2_factor, t2sparc_lambda, xtol;
+    double cut_m, cut_ie;
+    const double *Dfa;    // [nfa][m][n]
+    const double *Bfa;    // [nfa][n][n]
+    const double *kband;  // [5][64]
+    const double *lband;  // [5][64]
+    const double *lam_grid;
+    const double *t2s;    // [n]
+    const double *data;   // [nvox][m]
+    SortBufs sb;
+    double *fsol, *sig, *reg, *maps;
+    int32_t *status;
+    int64_t nvox;
+};
+
+// SciPy's bounded Brent (scipy.optimize.fminbound, called at algorithms.py:219,280 and
+// bayesian_interpolation.py:101), restated; executed redundantly by all lanes on uniform values.
+template <class F>
+__device__ __forceinline__ double fminbound_dev(F &&fn, double x1, double x2, double xatol, int maxfun, int &flag)
+{
+    const double sqrt_eps = sqrt(2.2e-16);
+    const double golden_mean = 0.5 * (3.0 - sqrt(5.0));
+    double a = x1, b = x2;
+    double fulc = a + golden_mean * (b - a);
+    double nfc = fulc, xf = fulc;
+    double rat = 0.0, e = 0.0;
+    double x = xf;
+    double fx = fn(x);
+    int num = 1;
+    flag = 0;
+    double fu = INFINITY;
+    double ffulc = fx, fnfc = fx;
+    double xm = 0.5 * (a + b);
+    double tol1 = sqrt_eps * fabs(xf) + xatol / 3.0;
+    double tol2 = 2.0 * tol1;
+    while (fabs(xf - xm) > (tol2 - 0.5 * (b - a))) {
+        bool golden = true;
+        if (fabs(e) > tol1) {
+            golden = false;
+            double r = (xf - nfc) * (fx - ffulc);
+            double q = (xf - fulc) * (fx - fnfc);
+            double p = (xf - fulc) * q - (xf - nfc) * r;
+            q = 2.0 * (q - r);
+            if (q > 0.0) p = -p;
+            q = fabs(q);
+            r = e;
+            e = rat;
+            if ((fabs(p) < fabs(0.5 * q * r)) && (p > q * (a - xf)) && (p < q * (b - xf))) {
+                rat = (p + 0.0) / q;
+                x = xf + rat;
+                if (((x - a) < tol2) || ((b - x) < tol2)) {
+                    double d = xm - xf;
+                    double si = (double)((d > 0.0) - (d < 0.0) + (d == 0.0));
+                    rat = tol1 * si;
+                }
+            } else golden = true;
+        }
+        if (golden) {
+            e = (xf >= xm) ? a - xf : b - xf;
+            rat = golden_mean * e;
+        }
+        double si = (double)((rat > 0.0) - (rat < 0.0) + (rat == 0.0));
+        double ar = fabs(rat);
+        x = xf + si * (ar > tol1 ? ar : tol1);
+        fu = fn(x);
+        num++;
+        if (fu <= fx) {
+            if (x >= xf) a = xf; else b = xf;
+            fulc = nfc; ffulc = fnfc;
+            nfc = xf; fnfc = fx;
+            xf = x; fx = fu;
+        } else {
+            if (x < xf) a = x; else b = x;
+            if ((fu <= fnfc) || (nfc == xf)) {
+                fulc = nfc; ffulc = fnfc;
+                nfc = x; fnfc = fu;
+            } else if ((fu <= ffulc) || (fulc == xf) || (fulc == nfc)) {
+                fulc = x; ffulc = fu;
+            }
+        }
+        xm = 0.5 * (a + b);
+        tol1 = sqrt_eps * fabs(xf) + xatol / 3.0;
+        tol2 = 2.0 * tol1;
+        if (num >= maxfun) { flag = 1; break; }
+    }
+    if (isnan(xf) || isnan(fx) || isnan(fu)) flag = 2;
+    return xf;
+}
+
+// L-curve corner (algorithms.py:150-206): lane i < nl holds point i
+__device__ __forceinline__ double scale_curve_dev(double a, int nl, int lane)
+{
+    double vmin = wave_min(lane < nl ? a : INFINITY);
+    double vmax = wave_max(lane < nl ? a : -INFINITY);
+    const double l = -10.0, u = 10.0;
+    double s = (u - l) / (vmax - vmin), off = (u * vmin - l * vmax) / (u - l);
+    return s * (a - off);
+}
+__device__ __forceinline__ int select_corner_dev(double le, double ln, int nl, int lane)
+{
+    double xs = scale_curve_dev(le, nl, lane), ys = scale_curve_dev(ln, nl, lane);
+    const double cte = 7.0 * M_PI / 8.0;
+    const double c0 = bcast(xs, nl - 1), c1 = bcast(ys, nl - 1);
+    double best = INFINITY; int bestk = 1 << 20;
+    const double a0 = xs, a1 = ys;
+    const double ac = sqrt((a0 - c0) * (a0 - c0) + (a1 - c1) * (a1 - c1));
+    for (int k = 0; k < nl - 2; ++k) {
+        double b0 = bcast(xs, k), b1 = bcast(ys, k);
+        double ab = sqrt((a0 - b0) * (a0 - b0) + (a1 - b1) * (a1 - b1));
+        double bc = sqrt((b0 - c0) * (b0 - c0) + (b1 - c1) * (b1 - c1));
+        double cosa = (ab * ab + ac * ac - bc * bc) / (2.0 * ab * ac);
+        double t = (1.0 < cosa) ? 1.0 : cosa;
+        cosa = (t > -1.0) ? t : -1.0;
+        double ang = acos(cosa);
+        double area = 0.5 * ((b0 - a0) * (a1 - c1) - (a0 - c0) * (b1 - a1));
+        bool ok = (lane > k) && (lane < nl - 1) && (area > 0.0) && (ang < cte) && (ang < best);
+        if (ok) { best = ang; bestk = k; }
+    }
+    double amin = wave_min(best);
+    if (!(amin < INFINITY)) return nl - 1;
+    bool tie = (best == amin);
+    double kmin = wave_min(tie ? (double)bestk : 1e9);
+    return first_lane(ballot(tie && (double)bestk == kmin));
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int n = A.n, m = A.m, np = A.np, kmax = A.kmax;
+    const int tri = kmax * (kmax + 1) / 2;
+    double *sB = smem;
+    double *sD = sB + n * np;
+    double *sR = sD + m * np + (size_t)wave * tri;
+    int *sI = (int *)(sD + m * np + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
+
+    WaveShared S;
+    S.sB = sB; S.sD = sD; S.R = sR; S.n = n; S.m = m; S.np = np; S.kmax = kmax;
+    Band bd;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) { bd.kb[d] = A.kband[d * 64 + lane]; bd.lb[d] = A.lband[d * 64 + lane]; }
+    const double t2 = (lane < n) ? A.t2s[lane] : 0.0;
+    const double logt2 = (lane < n) ? log(t2) : 0.0;
+    const bool isM = (lane < n) && (t2 <= A.cut_m);
+    const bool isIE = (lane < n) && (t2 > A.cut_m) && (t2 <= A.cut_ie);
+    const bool isCSF = (lane < n) && (t2 >= A.cut_ie);
+
+    const int nchunks = A.sb.chunk_start[A.nfa];
+    int loaded_fa = -1;
+    for (;;) {
+        if (threadIdx.x == 0) { sI[0] = atomicAdd(A.sb.queue, 1); sI[1] = 0; }
+        __syncthreads();
+        const int c = sI[0];
+        if (c >= nchunks) break;
+        int lo = 0, hi = A.nfa;                       // largest fa with chunk_start[fa] <= c
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.sb.chunk_start[mid] <= c) lo = mid; else hi = mid; }
+        const int fa = lo;
+        const int first = A.sb.bucket_start[fa] + (c - A.sb.chunk_start[fa]) * A.chunk;
+        const int cnt = min(A.chunk, A.sb.bucket_start[fa + 1] - first);
+        if (fa != loaded_fa) {
+            const double *Bf = A.Bfa + (size_t)fa * n * n;
+            const double *Df = A.Dfa + (size_t)fa * m * n;
+            for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
+            for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
+            loaded_fa = fa;
+            __syncthreads();
+        }
+        for (;;) {
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&sI[1], 1);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot >= cnt) break;
+            const int64_t v = A.sb.perm[first + slot];
+
+            // ---- load, normalise by the first echo (motor:129-132), h = D^T b
+            double b = (lane < m) ? A.data[(size_t)v * m + lane] : 0.0;
+            const double km = bcast(b, 0);
+            b = b / km;
+            NnlsState st; st.itmax_hit = 0;
+            {
+                double h = 0.0;
+                for (int e = 0; e < m; ++e) {
+                    double be = bcast(b, e);
+                    double dv = (lane < n) ? sD[e * np + lane] : 0.0;
+                    h = fma(dv, be, h);
+                }
+                st.h = h;
+            }
+            double regv = 0.0; int stat = MET2_ST_FITTED;
+
+            if (METHOD == MET2_NNLS) {
+                nnls_solve(S, bd, st, 0.0, false, lane);
+            } else if (METHOD == MET2_T2SPARC) {
+                nnls_solve(S, bd, st, A.t2sparc_lambda, true, lane);
+                regv = A.t2sparc_lambda;
+            } else if (METHOD == MET2_X2) {
+                // algorithms.py:211-233
+                nnls_solve(S, bd, st, 0.0, false, lane);
+                const double SSE = sse_of(S, st, b, lane);
+                const double target = A.x2_factor * SSE;
+                int flag;
+                double lam = fminbound_dev([&](double x) {
+                    nnls_solve(S, bd, st, x, true, lane);
+                    double SSEr = sse_of(S, st, b, lane);
+                    return fabs(SSEr - target) / SSE;
+                }, 0.0, 10.0, A.xtol, A.maxfun, flag);
+                if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
+                nnls_solve(S, bd, st, lam, true, lane);
+                regv = sse_of(S, st, b, lane) / SSE;          // k_est (motor:141-143)
+            } else if (METHOD == MET2_LCURVE) {
+                // algorithms.py:88-113
+                double le = 0.0, ln = 0.0;
+                for (int i = 0; i < A.nlam; ++i) {
+                    double lam = A.lam_grid[i];
+                    nnls_solve(S, bd, st, lam, true, lane);
+                    double sse = sse_of(S, st, b, lane);
+                    double lf = band_mul(bd.lb, st.x, lane);
+                    lf = (lane < n) ? lf : 0.0;
+                    double sn = wave_sum(lf * lf);
+                    if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
+                }
+                int corner = select_corner_dev(le, ln, A.nlam, lane);
+                regv = A.lam_grid[corner];
+                nnls_solve(S, bd, st, regv, true, lane);
+            }
+            if (st.itmax_hit) stat |= MET2_ST_ITMAX;
+
+            // ---- epilogue: un-normalise (motor:153-155) + metrics (motor:448-468)
+            const double xs = st.x * km;
+            if (lane < n) A.fsol[(size_t)v * n + lane] = xs;
+            if (A.sig) {
+                double sg = model_signal(S, st, lane) * km;
+                if (lane < m) A.sig[(size_t)v * m + lane] = sg;
+            }
+            if (A.maps) {
+                const double epsilon = 1.0e-16;
+                double vt = wave_sum(lane < n ? xs : 0.0) + epsilon;
+                double xn = xs / vt;
+                double fm = isM ? xn : 0.0, fie = isIE ? xn : 0.0;
+                double lm = isM ? xn * logt2 : 0.0, lie = isIE ? xn * logt2 : 0.0;
+                double fcsf = wave_sum(isCSF ? xn : 0.0);
+                wave_sum2(fm, fie);
+                wave_sum2(lm, lie);
+                if (lane == 0) {
+                    A.maps[0 * A.nvox + v] = fm;
+                    A.maps[1 * A.nvox + v] = fie;
+                    A.maps[2 * A.nvox + v] = fcsf;
+                    A.maps[3 * A.nvox + v] = exp(lm / (fm + epsilon));
+                    A.maps[4 * A.nvox + v] = exp(lie / (fie + epsilon));
+                    A.maps[5 * A.nvox + v] = vt;
+                }
+            }
+            if (lane == 0) {
+                A.reg[v] = regv;
+                if (A.status) A.status[v] = stat;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// zeros for gated-out voxels (motor:115-117) and the metrics an all-zero spectrum gets at
+// motor:448-468 when mask > 0 (T2_M = T2_IE = exp(0) = 1, TWC = 1e-16)
+__global__ __launch_bounds__(256) void finalize_unfitted_kernel(int64_t nvox, int n, int m, const int *__restrict__ key,
+                                                                const uint8_t *__restrict__ mask, double *__restrict__ fsol,
+                                                                double *__restrict__ sig, double *__restrict__ reg,
+                                                                double *__restrict__ maps)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < nvox * n; i += stride) if (key[i / n] < 0) fsol[i] = 0.0;
+    if (sig) for (int64_t i = t0; i < nvox * m; i += stride) if (key[i / m] < 0) sig[i] = 0.0;
+    for (int64_t v = t0; v < nvox; v += stride) {
+        if (key[v] >= 0) continue;
+        reg[v] = 0.0;
+        if (maps) {
+            bool mk = mask ? (mask[v] != 0) : true;
+            maps[0 * nvox + v] = 0.0; maps[1 * nvox + v] = 0.0; maps[2 * nvox + v] = 0.0;
+            maps[3 * nvox + v] = mk ? 1.0 : 0.0; maps[4 * nvox + v] = mk ? 1.0 : 0.0;
+            maps[5 * nvox + v] = mk ? 1.0e-16 : 0.0;
+        }
+    }
+}
+
+// motor:443-472 standalone: one wavefront per voxel
+__global__ __launch_bounds__(256) void metrics_kernel(int64_t nvox, int n, const double *__restrict__ t2s, double cut_m, double cut_ie,
+                                                      const double *__restrict__ fsol, const uint8_t *__restrict__ mask,
+                                                      double *__restrict__ maps)
+{
+    const int lane = lane_id();
+    const double t2 = (lane < n) ? t2s[lane] : 0.0;
+    const double logt2 = (lane < n) ? log(t2) : 0.0;
+    const bool isM = (lane < n) && (t2 <= cut_m), isIE = (lane < n) && (t2 > cut_m) && (t2 <= cut_ie), isCSF = (lane < n) && (t2 >= cut_ie);
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; v < nvox; v += nw) {
+        bool mk = mask ? (mask[v] != 0) : true;
+        double xs = (lane < n && mk) ? fsol[(size_t)v * n + lane] : 0.0;
+        const double epsilon = 1.0e-16;
+        double vt = wave_sum(xs) + epsilon;
+        double xn = xs / vt;
+        double fm = isM ? xn : 0.0, fie = isIE ? xn : 0.0;
+        double lm = isM ? xn * logt2 : 0.0, lie = isIE ? xn * logt2 : 0.0;
+        double fcsf = wave_sum(isCSF ? xn : 0.0);
+        wave_sum2(fm, fie);
+        wave_sum2(lm, lie);
+        if (lane == 0) {
+            maps[0 * nvox + v] = mk ? fm : 0.0;
+            maps[1 * nvox + v] = mk ? fie : 0.0;
+            maps[2 * nvox + v] = mk ? fcsf : 0.0;
+            maps[3 * nvox + v] = mk ? exp(lm / (fm + epsilon)) : 0.0;
+            maps[4 * nvox + v] = mk ? exp(lie / (fie + epsilon)) : 0.0;
+            maps[5 * nvox + v] = mk ? vt : 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct met2_plan {
+    int n_te, n_t2, n_fa;
+    met2_options opt;
+    int cus;
+    double *dD = nullptr;       // [nfa][nte][nt2]
+    double *dB = nullptr;       // [nfa][nt2][nt2]
+    double *dKband = nullptr;   // [5][64]
+    double *dLband = nullptr;   // [5][64]
+    double *dLam = nullptr;     // [nlam]
+    double *dT2 = nullptr;      // [nt2]
+    int nlam = 0;
+    bool have_dict = false, have_pen = false, have_t2 = false;
+    std::vector<double> Lhost;  // dense penalty as given
+    double logdetL = 0.0;
+    // sort buffers (grown on demand)
+    int64_t cap_vox = 0;
+    int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+static void default_lambda_grid(std::vector<double> &g)
+{
+    g.assign(50, 0.0);   // motor:248-251
+    const double l0 = log10(1e-8), l1 = log10(10.0);
+    for (int i = 0; i < 49; ++i) g[i + 1] = pow(10.0, l0 + (l1 - l0) * (double)i / 48.0);
+    g[49] = 10.0;
+}
+
+static int ensure_sort_bufs(met2_plan *p, int64_t nvox)
+{
+    if (nvox <= p->cap_vox) return MET2_OK;
+    if (p->dKey) HIPCHK(hipFree(p->dKey));
+    if (p->dPerm) HIPCHK(hipFree(p->dPerm));
+    HIPCHK(hipMalloc(&p->dKey, sizeof(int) * (size_t)nvox));
+    HIPCHK(hipMalloc(&p->dPerm, sizeof(int) * (size_t)nvox));
+    p->cap_vox = nvox;
+    return MET2_OK;
+}
+
+static SortBufs sort_bufs(met2_plan *p)
+{
+    SortBufs sb;
+    const int nf = p->n_fa + 1;
+    sb.key = p->dKey; sb.perm = p->dPerm;
+    sb.hist = p->dSmall; sb.cursor = p->dSmall + nf; sb.bucket_start = p->dSmall + 2 * nf; sb.chunk_start = p->dSmall + 3 * nf;
+    sb.queue = p->dSmall + 4 * nf; sb.err = p->dSmall + 4 * nf + 1;
+    return sb;
+}
+
+struct LaunchGeom { int grid, block, waves, np, kmax, lds; };
+
+static int fit_geometry(const met2_plan *p, LaunchGeom &g)
+{
+    const int n = p->n_t2, m = p->n_te;
+    g.np = n | 1;
+    g.kmax = n;
+    const size_t shared = sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np);
+    const size_t per_wave = sizeof(double) * ((size_t)g.kmax * (g.kmax + 1) / 2);
+    const size_t budget = 160 * 1024 - 64;
+    if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
+    int w = (int)((budget - shared) / per_wave);
+    if (w > 8) w = 8;
+    g.waves = w; g.block = 64 * w;
+    g.lds = (int)(shared + per_wave * w + 64);
+    g.grid = p->cus > 0 ? p->cus : 256;
+    return MET2_OK;
+}
+
+template <int METHOD>
+static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
+{
+    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL(fit_kernel<METHOD>, dim3(g.grid), dim3(g.block), g.lds, s, A);
+    HIPCHK(hipGetLastError());
+    return MET2_OK;
+}
+
+extern "C" {
+
+void met2_default_options(met2_options *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (int32_t)sizeof(met2_options);
+    o->device = 0;
+    o->x2_factor = 1.02;
+    o->t2sparc_lambda = 1.8;
+    o->brent_xtol = 1e-5;
+    o->brent_maxfun = 0;
+    o->t2_myelin_cut = 40.0;
+    o->t2_ie_cut = 200.0;
+}
+
+int met2_abi_version(void) { return MET2_ABI_VERSION; }
+
+int met2_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *met2_last_error(void) { return g_err.c_str(); }
+
+int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, const met2_options *opt)
+{
+    if (!out) return fail(MET2_E_INVALID, "out is NULL");
+    if (n_te < 2 || n_t2 < 2 || n_fa < 1) return fail(MET2_E_INVALID, "bad shape");
+    if (n_t2 > 64) return fail(MET2_E_UNSUPPORTED, "n_t2 > 64 is not built yet (one T2 bin per lane)");
+    if (n_te > 63) return fail(MET2_E_UNSUPPORTED, "n_te > 63 unsupported (EPG orders live on the 64 lanes)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MET2_E_NODEVICE, "no HIP device visible");
+    met2_plan *p = new met2_plan();
+    p->n_te = n_te; p->n_t2 = n_t2; p->n_fa = n_fa;
+    if (opt) { memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size); }
+    else met2_default_options(&p->opt);
+    if (p->opt.device < 0 || p->opt.device >= ndev) { delete p; return fail(MET2_E_INVALID, "device ordinal out of range"); }
+    HIPCHK(hipSetDevice(p->opt.device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, p->opt.device));
+    p->cus = prop.multiProcessorCount;
+    HIPCHK(hipMalloc(&p->dD, sizeof(double) * (size_t)n_fa * n_te * n_t2));
+    HIPCHK(hipMalloc(&p->dB, sizeof(double) * (size_t)n_fa * n_t2 * n_t2));
+    HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 64));
+    HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 64));
+    HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 64));
+    HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 8)));
+    HIPCHK(hipEventCreate(&p->ev0));
+    HIPCHK(hipEventCreate(&p->ev1));
+    std::vector<double> g;
+    default_lambda_grid(g);
+    *out = p;
+    return met2_plan_set_lambda_grid(p, g.data(), (int)g.size());
+}
+
+int met2_plan_destroy(met2_plan *p)
+{
+    if (!p) return MET2_OK;
+    (void)hipSetDevice(p->opt.device);
+    void *bufs[] = {p->dD, p->dB, p->dKband, p->dLband, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall};
+    for (void *b : bufs) (void)hipFree(b);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+    return MET2_OK;
+}
+
+static int build_gram(met2_plan *p, hipStream_t s)
+{
+    hipLaunchKernelGGL(gram_kernel, dim3(p->n_fa), dim3(256), 0, s, p->n_te, p->n_t2, p->dD, p->dB);
+    HIPCHK(hipGetLastError());
+    p->have_dict = true;
+    return MET2_OK;
+}
+
+int met2_plan_set_t2_grid(met2_plan *p, const double *T2s)
+{
+    if (!p || !T2s) return fail(MET2_E_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(p->opt.device));
+    HIPCHK(hipMemcpy(p->dT2, T2s, sizeof(double) * p->n_t2, hipMemcpyHostToDevice));
+    p->have_t2 = true;
+    return MET2_OK;
+}
+
+int met2_plan_build_dictionary_epg(met2_plan *p, const double *T2s, const double *T1s, double tau, const double *alpha_deg,
+                                   double TR, void *stream)
+{
+    if (!p || !T2s || !T1s || !alpha_deg) return fail(MET2_E_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(p->opt.device));
+    hipStream_t s = (hipStream_t)stream;
+    double *tmp = nullptr;
+    size_t nb = sizeof(double) * (size_t)(2 * p->n_t2 + p->n_fa);
+    HIPCHK(hipMalloc(&tmp, nb));
+    std::vector<double> h(2 * p->n_t2 + p->n_fa);
+    memcpy(h.data(), T2s, sizeof(double) * p->n_t2);
+    memcpy(h.data() + p->n_t2, T1s, sizeof(double) * p->n_t2);
+    memcpy(h.data() + 2 * p->n_t2, alpha_deg, sizeof(double) * p->n_fa);
+    HIPCHK(hipMemcpy(tmp, h.data(), nb, hipMemcpyHostToDevice));
+    int waves = p->n_fa * p->n_t2;
+    int blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL(epg_dictionary_kernel, dim3(blocks), dim3(256), 0, s, p->n_te, p->n_t2, p->n_fa, tmp, tmp + p->n_t2, tau,
+                       tmp + 2 * p->n_t2, TR, p->dD);
+    HIPCHK(hipGetLastError());
+    int rc = build_gram(p, s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(tmp));
+    if (rc) return rc;
+    return met2_plan_set_t2_grid(p, T2s);
+}
+
+int met2_plan_set_dictionary(met2_plan *p, const double *dic)
+{
+    if (!p || !dic) return fail(MET2_E_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(p->opt.device));
+    size_t nb = sizeof(double) * (size_t)p->n_fa * p->n_te * p->n_t2;
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, nb));
+    HIPCHK(hipMemcpy(tmp, dic, nb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(relayout_kernel, dim3(256), dim3(256), 0, 0, p->n_te, p->n_t2, p->n_fa, tmp, p->dD, 1);
+    HIPCHK(hipGetLastError());
+    int rc = build_gram(p, 0);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(tmp));
+    return rc;
+}
+
+int met2_plan_get_dictionary(met2_plan *p, double *dic)
+{
+    if (!p || !dic) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
+    HIPCHK(hipSetDevice(p->opt.device));
+    size_t nb = sizeof(double) * (size_t)p->n_fa * p->n_te * p->n_t2;
+    double *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, nb));
+    hipLaunchKernelGGL(relayout_kernel, dim3(256), dim3(256), 0, 0, p->n_te, p->n_t2, p->n_fa, p->dD, tmp, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(dic, tmp, nb, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(tmp));
+    return MET2_OK;
+}
+
+int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
+{
+    if (!p || !L) return fail(MET2_E_INVALID, "NULL argument");
+    const int n = p->n_t2;
+    for (int i = 0; i < n * n; ++i) if (!std::isfinite(L[i])) return fail(MET2_E_INVALID, "non-finite penalty matrix");
+    std::vector<double> K((size_t)n * n, 0.0);
+    for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) {
+        double t = 0.0;
+        for (int i = 0; i < n; ++i) t += L[(size_t)i * n + a] * L[(size_t)i * n + b];
+        K[(size_t)a * n + b] = t;
+    }
+    for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (abs(a - b) > 2) {
+        if (K[(size_t)a * n + b] != 0.0) return fail(MET2_E_UNSUPPORTED, "L^T L has bandwidth > 2");
+        if (L[(size_t)a * n + b] != 0.0) return fail(MET2_E_UNSUPPORTED, "penalty matrix has bandwidth > 2");
+    }
+    std::vector<double> kb(5 * 64, 0.0), lb(5 * 64, 0.0);
+    for (int j = 0; j < n; ++j) for (int d = 0; d < 5; ++d) {
+        int c = j + d - 2;
+        if (c < 0 || c >= n) continue;
+        kb[d * 64 + j] = K[(size_t)j * n + c];
+        lb[d * 64 + j] = L[(size_t)j * n + c];
+    }
+    HIPCHK(hipSetDevice(p->opt.device));
+    HIPCHK(hipMemcpy(p->dKband, kb.data(), sizeof(double) * 5 * 64, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dLband, lb.data(), sizeof(double) * 5 * 64, hipMemcpyHostToDevice));
+    p->Lhost.assign(L, L + (size_t)n * n);
+    p->have_pen = true;
+    return MET2_OK;
+}
+
+int met2_plan_set_penalty(met2_plan *p, int32_t which, const double *T2s)
+{
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    const int n = p->n_t2;
+    std::vector<double> L((size_t)n * n, 0.0);
+    switch (which) {   // motor:86-111, 263-269
+    case MET2_PEN_I: for (int i = 0; i < n; ++i) L[(size_t)i * n + i] = 1.0; break;
+    case MET2_PEN_L1: for (int i = 0; i < n; ++i) { L[(size_t)i * n + i] = 1.0; if (i > 0) L[(size_t)i * n + i - 1] = -1.0; } break;
+    case MET2_PEN_L2:
+        for (int i = 0; i < n; ++i) {
+            L[(size_t)i * n + i] = 2.0;
+            if (i > 0) L[(size_t)i * n + i - 1] = -1.0;
+            if (i < n - 1) L[(size_t)i * n + i + 1] = -1.0;
+        }
+        L[0] = 1.0; L[(size_t)(n - 1) * n + n - 1] = 1.0;
+        break;
+    case MET2_PEN_INVT2:
+        if (!T2s) return fail(MET2_E_INVALID, "InvT2 needs the T2 grid");
+        for (int i = 0; i < n; ++i) {
+            double prev = (i == 0) ? T2s[0] - 1.0 : T2s[i - 1];
+            double d = T2s[i] - prev;
+            if (i == 0) d = T2s[1] - T2s[0];
+            L[(size_t)i * n + i] = 1.0 / d;
+        }
+        break;
+    default: return fail(MET2_E_INVALID, "unknown penalty");
+    }
+    return met2_plan_set_penalty_dense(p, L.data());
+}
+
+int met2_plan_get_penalty(met2_plan *p, double *L)
+{
+    if (!p || !L) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p->have_pen) return fail(MET2_E_STATE, "no penalty set");
+    memcpy(L, p->Lhost.data(), sizeof(double) * p->Lhost.size());
+    return MET2_OK;
+}
+
+int met2_plan_set_lambda_grid(met2_plan *p, const double *lam, int32_t n)
+{
+    if (!p || !lam || n < 3) return fail(MET2_E_INVALID, "bad lambda grid");
+    if (n > 64) return fail(MET2_E_UNSUPPORTED, "lambda grid longer than 64 points");
+    HIPCHK(hipSetDevice(p->opt.device));
+    if (p->dLam) HIPCHK(hipFree(p->dLam));
+    HIPCHK(hipMalloc(&p->dLam, sizeof(double) * n));
+    HIPCHK(hipMemcpy(p->dLam, lam, sizeof(double) * n, hipMemcpyHostToDevice));
+    p->nlam = n;
+    return MET2_OK;
+}
+
+int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, const double *fa_index, const uint8_t *mask,
+             double *fsol, double *sig, double *reg, double *maps, int32_t *status, void *stream)
+{
+    if (!p || !data || !fsol || !reg) return fail(MET2_E_INVALID, "NULL argument");
+    if (nvox < 0 || nvox > 0x7fffffff) return fail(MET2_E_INVALID, "nvox out of range");
+    if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
+    if (method != MET2_NNLS && !p->have_pen) return fail(MET2_E_STATE, "no penalty matrix set");
+    if (maps && !p->have_t2) return fail(MET2_E_STATE, "metrics requested but no T2 grid set");
+    if (method == MET2_GCV || method == MET2_BAYESREG) return fail(MET2_E_UNSUPPORTED, "GCV/BayesReg kernels are not built yet");
+    if (method < 0 || method > MET2_BAYESREG) return fail(MET2_E_INVALID, "unknown method");
+    if (nvox == 0) return MET2_OK;
+    HIPCHK(hipSetDevice(p->opt.device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_sort_bufs(p, nvox);
+    if (rc) return rc;
+    LaunchGeom g;
+    rc = fit_geometry(p, g);
+    if (rc) return rc;
+    if (!p->have_pen) {   // plain NNLS never touches the bands, but the kernel loads them
+        HIPCHK(hipMemsetAsync(p->dKband, 0, sizeof(double) * 5 * 64, s));
+        HIPCHK(hipMemsetAsync(p->dLband, 0, sizeof(double) * 5 * 64, s));
+    }
+    if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 64, s));
+    SortBufs sb = sort_bufs(p);
+    HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 8), s));
+    const int nb = (int)((nvox + 255) / 256);
+    const int chunk = 128;
+    hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, fa_index, mask, 1, sb, status);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
+    HIPCHK(hipGetLastError());
+
+    FitArgs A;
+    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.chunk = chunk;
+    A.method = method; A.nlam = p->nlam;
+    A.maxfun = p->opt.brent_maxfun > 0 ? p->opt.brent_maxfun : (method == MET2_BAYESREG ? 200 : 300);
+    A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
+    A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.kband = p->dKband; A.lband = p->dLband; A.lam_grid = p->dLam; A.t2s = p->dT2;
+    A.data = data; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.maps = maps; A.status = status; A.nvox = nvox;
+
+    HIPCHK(hipEventRecord(p->ev0, s));
+    switch (method) {
+    case MET2_NNLS: rc = launch_fit<MET2_NNLS>(A, g, s); break;
+    case MET2_T2SPARC: rc = launch_fit<MET2_T2SPARC>(A, g, s); break;
+    case MET2_X2: rc = launch_fit<MET2_X2>(A, g, s); break;
+    case MET2_LCURVE: rc = launch_fit<MET2_LCURVE>(A, g, s); break;
+    default: rc = fail(MET2_E_UNSUPPORTED, "method not built");
+    }
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(p->ev1, s));
+    p->timed = true;
+    hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
+                       sig, reg, maps);
+    HIPCHK(hipGetLastError());
+    // FA index range errors are reported synchronously (they would be IndexError in the reference)
+    int herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, sb.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
+    return MET2_OK;
+}
+
+int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uint8_t *mask, double *fa_index, double *km,
+                       double *resid, void *stream)
+{
+    (void)p; (void)nvox; (void)data; (void)mask; (void)fa_index; (void)km; (void)resid; (void)stream;
+    return fail(MET2_E_UNSUPPORTED, "brute-force FA kernel is not built yet");
+}
+
+int met2_metrics(met2_plan *p, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps, void *stream)
+{
+    if (!p || !fsol || !maps) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p->have_t2) return fail(MET2_E_STATE, "no T2 grid set");
+    if (nvox <= 0) return MET2_OK;
+    HIPCHK(hipSetDevice(p->opt.device));
+    int blocks = (int)((nvox + 3) / 4);
+    if (blocks > p->cus * 16) blocks = p->cus * 16;
+    hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nvox, p->n_t2, p->dT2, p->opt.t2_myelin_cut,
+                       p->opt.t2_ie_cut, fsol, mask, maps);
+    HIPCHK(hipGetLastError());
+    return MET2_OK;
+}
+
+int met2_plan_last_kernel_ms(met2_plan *p, double *ms)
+{
+    if (!p || !ms) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p->timed) return fail(MET2_E_STATE, "no timed launch yet");
+    HIPCHK(hipSetDevice(p->opt.device));
+    HIPCHK(hipEventSynchronize(p->ev1));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, p->ev0, p->ev1));
+    *ms = (double)f;
+    return MET2_OK;
+}
+
+int met2_plan_launch_info(met2_plan *p, int32_t method, int32_t *grid, int32_t *block, int32_t *lds_bytes)
+{
+    (void)method;
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    LaunchGeom g;
+    int rc = fit_geometry(p, g);
+    if (rc) return rc;
+    if (grid) *grid = g.grid;
+    if (block) *block = g.block;
+    if (lds_bytes) *lds_bytes = g.lds;
+    return MET2_OK;
+}
+
+} // extern "C"
