@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -340,10 +341,11 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
 
     const int nchunks = A.sb.chunk_start[A.nfa];
     int loaded_fa = -1;
-    for (;;) {
+    for (int round = 0; round <= nchunks; ++round) {      // the queue hands out each chunk once
         if (threadIdx.x == 0) { sI[0] = atomicAdd(A.sb.queue, 1); sI[1] = 0; }
         __syncthreads();
         const int c = sI[0];
+        MET2_STAT(5, round);
         if (c >= nchunks) break;
         int lo = 0, hi = A.nfa;                       // largest fa with chunk_start[fa] <= c
         while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (A.sb.chunk_start[mid] <= c) lo = mid; else hi = mid; }
@@ -358,10 +360,11 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
             loaded_fa = fa;
             __syncthreads();
         }
-        for (;;) {
+        for (int taken = 0; taken <= cnt; ++taken) {
             int slot = 0;
             if (lane == 0) slot = atomicAdd(&sI[1], 1);
             slot = __builtin_amdgcn_readfirstlane(slot);
+            MET2_STAT(4, taken);
             if (slot >= cnt) break;
             const int64_t v = A.sb.perm[first + slot];
 
@@ -838,10 +841,19 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 8), s));
     const int nb = (int)((nvox + 255) / 256);
     const int chunk = 128;
+    const bool dbg = getenv("MET2_DEBUG") != nullptr;
+    if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit: nvox=%lld grid=%d block=%d lds=%d\n", (long long)nvox, g.grid, g.block, g.lds); fflush(stderr); }
     hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, fa_index, mask, 1, sb, status);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
+    if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] classify done\n"); fflush(stderr); }
     hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
     HIPCHK(hipGetLastError());
+    if (dbg) {
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int> hs(4 * (size_t)(p->n_fa + 1) + 8);
+        HIPCHK(hipMemcpy(hs.data(), p->dSmall, sizeof(int) * hs.size(), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[met2] sort done: fitted=%d chunks=%d\n", hs[2 * (p->n_fa + 1) + p->n_fa], hs[3 * (p->n_fa + 1) + p->n_fa]); fflush(stderr);
+    }
 
     FitArgs A;
     A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.chunk = chunk;
@@ -863,6 +875,15 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     if (rc) return rc;
     HIPCHK(hipEventRecord(p->ev1, s));
     p->timed = true;
+    if (dbg) {
+        HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit kernel done\n");
+#ifdef MET2_LOOPSTATS
+        int ls[8];
+        HIPCHK(hipMemcpyFromSymbol(ls, HIP_SYMBOL(met2::g_loopstats), sizeof(ls)));
+        fprintf(stderr, "[met2] loop maxima: tries=%d sweeps=%d outer=%d iter=%d taken=%d round=%d\n", ls[0], ls[1], ls[2], ls[3], ls[4], ls[5]);
+#endif
+        fflush(stderr);
+    }
     hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
                        sig, reg, maps);
     HIPCHK(hipGetLastError());

@@ -22,6 +22,13 @@
 
 namespace met2 {
 
+#ifdef MET2_LOOPSTATS
+__device__ int g_loopstats[8];
+#define MET2_STAT(slot, v) atomicMax(&g_loopstats[slot], (int)(v))
+#else
+#define MET2_STAT(slot, v)
+#endif
+
 struct WaveShared {
     const double *sB;   // [n][np]
     const double *sD;   // [m][np]
@@ -171,7 +178,7 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band &bd, 
     rr = (lane < k) ? rr : 0.0; ry = (lane < k) ? ry : 0.0;
     wave_sum2(rr, ry);
     const double rho2 = gtt - rr;
-    if (!(rho2 > 1e-11 * gtt)) return false;                     // dependent column
+    if (!(rho2 > 1e-14 * gtt)) return false;                     // dependent column (noise floor of gtt - r.r)
     const double rho = sqrt(rho2);
     const double ynew = (bcast(st.h, t) - ry) / rho;
     if (!(ynew / rho > 0.0)) return false;                       // ztest
@@ -206,13 +213,13 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
-    for (;;) {
+    for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows || st.k >= S.kmax) break;
         double w = dual(S, bd, st, lam, lane);
         // entering variable: largest positive dual among Z; rejected candidates are skipped
         u64 rejected = 0;
         bool accepted = false;
-        for (;;) {
+        for (int tries = 0; tries < 64; ++tries) {           // each failed try rejects one more bin
             bool cand = (lane < n) && !((st.P >> lane) & 1ull) && !((rejected >> lane) & 1ull);
             double val = cand ? w : -1.0;
             double wmax = wave_max(val);
@@ -220,6 +227,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd
             int t = first_lane(ballot(cand && val == wmax));
             if (try_append(S, bd, st, lam, t, lane)) { accepted = true; break; }
             rejected |= (1ull << t);
+            MET2_STAT(0, tries + 1);
         }
         if (!accepted) break;
         // secondary loop
@@ -240,14 +248,17 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd
             int jj = first_lane(ballot(neg && ratio == alpha));
             st.x = (st.pos >= 0) ? fma(alpha, zb - st.x, st.x) : 0.0;
             remove_pos(S, st, jj, lane);
-            for (;;) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
+            for (int sweep = 0; sweep < 64; ++sweep) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
                 double xq = gather(st.x, st.ord);
                 u64 bad = ballot((lane < st.k) && (xq <= 0.0));
                 if (!bad) break;
+                MET2_STAT(1, sweep + 1);
                 remove_pos(S, st, first_lane(bad), lane);
             }
         }
         if (capped) { st.itmax_hit = 1; break; }
+        MET2_STAT(2, outer + 1);
+        MET2_STAT(3, iter);
     }
 }
 
