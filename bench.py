@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--penalty", type=str, default="L2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dump-fail", type=str, default="", help="npz path: inputs/outputs of sample voxels whose fsol is >1e-5 off the oracle")
     args = ap.parse_args()
 
     pkg = importlib.import_module(PKG)
@@ -168,6 +169,10 @@ def main():
             mwf_ref = fs_ref[:, T2s <= 40.0].sum(axis=1) / (fs_ref.sum(axis=1) + 1e-16)
             line["parity"] = {"sample": n1, "max_rel_fsol": float(rel.max()), "frac_over_1e-5": float((rel > 1e-5).mean()),
                               "max_abs_MWF": float(np.max(np.abs(out["maps"][0, :n1].cpu().numpy() - mwf_ref)))}
+            if args.dump_fail:
+                bad = np.nonzero(rel > 1e-5)[0]
+                np.savez(args.dump_fail, idx=bad, data=data[:n1].cpu().numpy()[bad], got=got[bad], ref=fs_ref[bad],
+                         reg=out["reg"][:n1].cpu().numpy()[bad])
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
