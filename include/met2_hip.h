@@ -85,6 +85,10 @@ const char *met2_last_error(void);
 /* ---- plan: the shared nTE x nT2 x nFA problem (dictionary, Gram matrices, penalty) ---- */
 int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, const met2_options *opt);
 int met2_plan_destroy(met2_plan *plan);
+/* change x2_factor / t2sparc_lambda / Brent settings / metric windows of an existing plan
+ * (the per-call arguments `factor` of nnls_x2 and `reg_opt` of nnls_tik, algorithms.py:211,262) */
+int met2_plan_set_options(met2_plan *plan, const met2_options *opt);
+int met2_plan_get_options(met2_plan *plan, met2_options *opt);
 
 /* epg/epg.py:155 create_Dic_3D -- EPG dictionary built on the device, one wave per
  * (T2, flip angle).  T2s/T1s [n_t2], alpha_deg [n_fa] are host arrays.  Also forms the
@@ -122,13 +126,21 @@ int met2_plan_set_t2_grid(met2_plan *plan, const double *T2s);
  *   fsol     [nvox][n_t2]  out: x * km                       (motor:154)
  *   sig      [nvox][n_te]  out: Kernel @ x * km              (motor:155), may be NULL
  *   reg      [nvox]        out: reg_param                    (motor:153)
+ *   lam      [nvox]        out: the selected lambda (equals reg except for X2, where the driver
+ *                               stores k_est in reg_param, motor:141-143), may be NULL
  *   maps     [6][nvox]     out: MWF, IEWF, FWF, T2_M, T2_IE, TWC (motor:455-468), may be NULL
  *   status   [nvox]        out: met2_status bits, may be NULL
  * Gated-out voxels get zeros (motor:115-117) and, if mask != 0, the all-zero-spectrum
  * metrics of motor:448-468. */
 int met2_fit(met2_plan *plan, int32_t method, int64_t nvox, const double *data, const double *fa_index,
-             const uint8_t *mask, double *fsol, double *sig, double *reg, double *maps, int32_t *status,
-             void *stream);
+             const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
+             int32_t *status, void *stream);
+
+/* Test/diagnostic entry: `method` = 10 + MET2_X2 / MET2_GCV / MET2_BAYESREG passed to met2_fit
+ * evaluates that method's lambda-selection objective (algorithms.py:226-233, :285-296,
+ * bayesian_interpolation.py:107-126) on the plan's lambda grid (n <= n_t2 points) and stores the
+ * values in fsol[v][0..n); sig, lam and maps are not written. */
+#define MET2_OBJECTIVE_GRID 10
 
 /* flip_angle_algorithms/fa_estimation.py:74-111 (brute force over the plan's FA axis).
  * DEVICE pointers: data [nvox][n_te] (un-normalised), mask [nvox] (NULL = ones);

@@ -1,0 +1,50 @@
+"""Plan cache for the per-function drop-ins (nnls_x2(D, M, L, ...) style calls hand over the
+dictionary and penalty on every call; the device copies are reused when they are unchanged)."""
+import hashlib
+
+import numpy as np
+
+from .plan import Met2Plan
+
+_PLANS = {}
+_MAX = 8
+
+
+def _key(D3, L, lam_grid):
+    h = hashlib.blake2b(digest_size=16)
+    for a in (D3, L, lam_grid):
+        if a is None:
+            h.update(b"-")
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            h.update(str(a.shape).encode())
+            h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def plan_for(Dic_3D, Laplac=None, lambda_reg=None, T2s=None):
+    """Dic_3D in the reference layout [nTE, nT2, nFA] (a 2-D kernel is taken as nFA = 1)."""
+    D3 = np.asarray(Dic_3D, dtype=np.float64)
+    if D3.ndim == 2:
+        D3 = D3[:, :, None]
+    k = _key(D3, Laplac, lambda_reg)
+    p = _PLANS.get(k)
+    if p is None:
+        if len(_PLANS) >= _MAX:
+            _PLANS.pop(next(iter(_PLANS))).close()
+        p = Met2Plan(D3.shape[0], D3.shape[1], D3.shape[2])
+        p.set_dictionary(np.ascontiguousarray(D3))
+        if Laplac is not None:
+            p.set_penalty(np.asarray(Laplac, dtype=np.float64))
+        if lambda_reg is not None:
+            p.set_lambda_grid(lambda_reg)
+        _PLANS[k] = p
+    if T2s is not None:
+        p.set_t2_grid(T2s)
+    return p
+
+
+def clear():
+    for p in _PLANS.values():
+        p.close()
+    _PLANS.clear()

@@ -22,7 +22,7 @@ class Options(C.Structure):
 
 # every symbol include/met2_hip.h declares
 SYMBOLS = ["met2_default_options", "met2_abi_version", "met2_device_count", "met2_last_error", "met2_plan_create",
-           "met2_plan_destroy", "met2_plan_build_dictionary_epg", "met2_plan_set_dictionary", "met2_plan_get_dictionary",
+           "met2_plan_destroy", "met2_plan_set_options", "met2_plan_get_options", "met2_plan_build_dictionary_epg", "met2_plan_set_dictionary", "met2_plan_get_dictionary",
            "met2_plan_set_penalty", "met2_plan_set_penalty_dense", "met2_plan_get_penalty", "met2_plan_set_lambda_grid",
            "met2_plan_set_t2_grid", "met2_fit", "met2_fa_bruteforce", "met2_metrics", "met2_plan_last_kernel_ms",
            "met2_plan_launch_info"]
@@ -39,6 +39,8 @@ def lib():
         vp = C.c_void_p
         L.met2_plan_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Options)]
         L.met2_plan_destroy.argtypes = [vp]
+        L.met2_plan_set_options.argtypes = [vp, C.POINTER(Options)]
+        L.met2_plan_get_options.argtypes = [vp, C.POINTER(Options)]
         L.met2_plan_build_dictionary_epg.argtypes = [vp, _dp, _dp, C.c_double, _dp, C.c_double, vp]
         L.met2_plan_set_dictionary.argtypes = [vp, _dp]
         L.met2_plan_get_dictionary.argtypes = [vp, _dp]
@@ -47,7 +49,7 @@ def lib():
         L.met2_plan_get_penalty.argtypes = [vp, _dp]
         L.met2_plan_set_lambda_grid.argtypes = [vp, _dp, C.c_int32]
         L.met2_plan_set_t2_grid.argtypes = [vp, _dp]
-        L.met2_fit.argtypes = [vp, C.c_int32, C.c_int64] + [vp] * 9
+        L.met2_fit.argtypes = [vp, C.c_int32, C.c_int64] + [vp] * 10
         L.met2_fa_bruteforce.argtypes = [vp, C.c_int64] + [vp] * 6
         L.met2_metrics.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
         L.met2_plan_last_kernel_ms.argtypes = [vp, _dp]

@@ -22,6 +22,7 @@
 
 #include "../../include/met2_hip.h"
 #include "nnls_wave.hpp"
+#include "objectives.hpp"
 
 using namespace met2;
 
@@ -190,9 +191,11 @@ __global__ __launch_bounds__(256) void scatter_kernel(int64_t nvox, SortBufs sb)
 // ------------------------------------------------------------------------------------------
 struct FitArgs {
     int n, m, nfa, np, kmax, waves, chunk;
+    int wave_doubles;   // LDS doubles owned by each wave (>= kmax(kmax+1)/2; n*n for GCV)
     int method, nlam, maxfun;
     double x2_factor, t2sparc_lambda, xtol;
     double cut_m, cut_ie;
+    double log_detL;
     const double *Dfa;    // [nfa][m][n]
     const double *Bfa;    // [nfa][n][n]
     const double *kband;  // [5][64]
@@ -201,7 +204,7 @@ struct FitArgs {
     const double *t2s;    // [n]
     const double *data;   // [nvox][m]
     SortBufs sb;
-    double *fsol, *sig, *reg, *maps;
+    double *fsol, *sig, *reg, *lam, *maps;
     int32_t *status;
     int64_t nvox;
 };
@@ -322,14 +325,14 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, np = A.np, kmax = A.kmax;
-    const int tri = kmax * (kmax + 1) / 2;
+    const int tri = A.wave_doubles;
     double *sB = smem;
     double *sD = sB + n * np;
     double *sR = sD + m * np + (size_t)wave * tri;
     int *sI = (int *)(sD + m * np + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.sB = sB; S.sD = sD; S.R = sR; S.n = n; S.m = m; S.np = np; S.kmax = kmax;
+    S.sB = sB; S.sD = sD; S.R = sR; S.n = n; S.m = m; S.np = np; S.kmax = kmax; S.rcap = tri;
     Band bd;
 #pragma unroll
     for (int d = 0; d < 5; ++d) { bd.kb[d] = A.kband[d * 64 + lane]; bd.lb[d] = A.lband[d * 64 + lane]; }
@@ -382,13 +385,13 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 }
                 st.h = h;
             }
-            double regv = 0.0; int stat = MET2_ST_FITTED;
+            double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
 
             if (METHOD == MET2_NNLS) {
                 nnls_solve(S, bd, st, 0.0, false, lane);
             } else if (METHOD == MET2_T2SPARC) {
                 nnls_solve(S, bd, st, A.t2sparc_lambda, true, lane);
-                regv = A.t2sparc_lambda;
+                regv = lamv = A.t2sparc_lambda;
             } else if (METHOD == MET2_X2) {
                 // algorithms.py:211-233
                 nnls_solve(S, bd, st, 0.0, false, lane);
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 nnls_solve(S, bd, st, lam, true, lane);
                 regv = sse_of(S, st, b, lane) / SSE;          // k_est (motor:141-143)
+                lamv = lam;
             } else if (METHOD == MET2_LCURVE) {
                 // algorithms.py:88-113
                 double le = 0.0, ln = 0.0;
@@ -416,8 +420,61 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                     if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
                 }
                 int corner = select_corner_dev(le, ln, A.nlam, lane);
-                regv = A.lam_grid[corner];
+                regv = lamv = A.lam_grid[corner];
                 nnls_solve(S, bd, st, regv, true, lane);
+            } else if (METHOD == MET2_BAYESREG) {
+                // bayesian_interpolation.py:84-105
+                nnls_solve(S, bd, st, 0.0, false, lane);
+                const int nnz = __popcll(ballot((lane < n) && (st.x > 0.0)));
+                double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
+                const double sigma = sqrt(sse_of(S, st, b, lane) / dof);
+                BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
+                int flag;
+                double lam = fminbound_dev([&](double x) {
+                    nnls_solve(S, bd, st, x, true, lane);
+                    return bayes_objective(S, bd, st, bc, x, b, lane);
+                }, 1e-8, 2.0, A.xtol, A.maxfun, flag);
+                if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
+                if (bc.failed) stat |= MET2_ST_CHOLFAIL;
+                nnls_solve(S, bd, st, lam, true, lane);
+                regv = lamv = lam;
+            } else if (METHOD == MET2_GCV) {
+                // algorithms.py:276-283
+                int flag, overflow = 0;
+                double lam = fminbound_dev([&](double x) {
+                    nnls_solve(S, bd, st, x, true, lane);
+                    return gcv_objective(S, bd, st, x, b, lane, overflow);
+                }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
+                if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
+                if (overflow) stat |= MET2_ST_KOVERFLOW;
+                nnls_solve(S, bd, st, lam, true, lane);
+                regv = lamv = lam;
+            }
+            if (METHOD >= 10) {
+                // objective values of method METHOD-10 on the plan's lambda grid -> fsol[v][0..nlam)
+                constexpr int BASE = METHOD - 10;
+                double SSE = 1.0; BayesCtx bc; bc.failed = 0; bc.log_detL = A.log_detL; bc.beta = 1.0;
+                if (BASE == MET2_X2 || BASE == MET2_BAYESREG) {
+                    nnls_solve(S, bd, st, 0.0, false, lane);
+                    SSE = sse_of(S, st, b, lane);
+                    const int nnz = __popcll(ballot((lane < n) && (st.x > 0.0)));
+                    double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
+                    const double sigma = sqrt(SSE / dof);
+                    bc.beta = 1.0 / (sigma * sigma);
+                }
+                double keep = 0.0; int overflow = 0;
+                for (int i = 0; i < A.nlam; ++i) {
+                    const double x = A.lam_grid[i];
+                    nnls_solve(S, bd, st, x, true, lane);
+                    double val;
+                    if (BASE == MET2_X2) val = fabs(sse_of(S, st, b, lane) - A.x2_factor * SSE) / SSE;
+                    else if (BASE == MET2_GCV) val = gcv_objective(S, bd, st, x, b, lane, overflow);
+                    else val = bayes_objective(S, bd, st, bc, x, b, lane);
+                    if (lane == i) keep = val;
+                }
+                if (lane < n) A.fsol[(size_t)v * n + lane] = keep;
+                if (lane == 0) { A.reg[v] = 0.0; if (A.status) A.status[v] = stat | (overflow ? MET2_ST_KOVERFLOW : 0); }
+                continue;
             }
             if (st.itmax_hit) stat |= MET2_ST_ITMAX;
 
@@ -448,8 +505,102 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
             }
             if (lane == 0) {
                 A.reg[v] = regv;
+                if (A.lam) A.lam[v] = lamv;
                 if (A.status) A.status[v] = stat;
             }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// brute-force flip-angle estimation (flip_angle_algorithms/fa_estimation.py:74-111):
+// for every flip angle of the dictionary one plain NNLS per voxel, argmin of the residual norm.
+// A workgroup keeps a tile of waves*VPW voxels in registers and walks the FA axis, staging each
+// flip angle's D and B in LDS once per tile.
+// ------------------------------------------------------------------------------------------
+struct FaArgs {
+    int n, m, nfa, np, kmax, waves, wave_doubles;
+    const double *Dfa, *Bfa;
+    const double *data;
+    const uint8_t *mask;
+    double *fa_index, *km, *resid;
+    int *queue;
+    int64_t nvox;
+};
+
+template <int VPW>
+__global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int n = A.n, m = A.m, np = A.np;
+    double *sB = smem;
+    double *sD = sB + n * np;
+    double *sR = sD + m * np + (size_t)wave * A.wave_doubles;
+    int *sI = (int *)(sD + m * np + (size_t)A.waves * A.wave_doubles);
+    WaveShared S;
+    S.sB = sB; S.sD = sD; S.R = sR; S.n = n; S.m = m; S.np = np; S.kmax = A.kmax; S.rcap = A.wave_doubles;
+    Band bd;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) { bd.kb[d] = 0.0; bd.lb[d] = 0.0; }
+    const int tile_vox = A.waves * VPW;
+    const int64_t ntiles = (A.nvox + tile_vox - 1) / tile_vox;
+    for (int64_t round = 0; round <= ntiles; ++round) {
+        if (threadIdx.x == 0) sI[0] = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int64_t tile = sI[0];
+        if (tile >= ntiles) break;
+        const int64_t v0 = tile * tile_vox + (int64_t)wave * VPW;
+        double b[VPW], best_r[VPW], best_km[VPW];
+        int best_fa[VPW];
+        bool act[VPW];
+#pragma unroll
+        for (int vv = 0; vv < VPW; ++vv) {
+            const int64_t v = v0 + vv;
+            const bool in = v < A.nvox;
+            b[vv] = (in && lane < m) ? A.data[(size_t)v * m + lane] : 0.0;
+            double sum = wave_sum(b[vv]);
+            bool mk = in && (A.mask ? (A.mask[v] != 0) : true);
+            bool fin = (ballot(!isfinite(b[vv])) == 0ull);
+            act[vv] = mk && fin && (sum > 0.0);
+            best_r[vv] = INFINITY; best_km[vv] = 0.0; best_fa[vv] = 0;
+        }
+        for (int fa = 0; fa < A.nfa; ++fa) {
+            __syncthreads();
+            const double *Bf = A.Bfa + (size_t)fa * n * n;
+            const double *Df = A.Dfa + (size_t)fa * m * n;
+            for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
+            for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
+            __syncthreads();
+#pragma unroll
+            for (int vv = 0; vv < VPW; ++vv) {
+                if (!act[vv]) continue;
+                NnlsState st; st.itmax_hit = 0;
+                double h = 0.0;
+                for (int e = 0; e < m; ++e) {
+                    double be = bcast(b[vv], e);
+                    double dv = (lane < n) ? sD[e * np + lane] : 0.0;
+                    h = fma(dv, be, h);
+                }
+                st.h = h;
+                nnls_solve(S, bd, st, 0.0, false, lane);
+                const double rn = sqrt(sse_of(S, st, b[vv], lane));
+                if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
+                if (rn < best_r[vv]) {        // np.argmin: first minimum wins
+                    best_r[vv] = rn; best_fa[vv] = fa;
+                    best_km[vv] = wave_sum(lane < n ? st.x : 0.0);
+                }
+            }
+        }
+#pragma unroll
+        for (int vv = 0; vv < VPW; ++vv) {
+            const int64_t v = v0 + vv;
+            if (v < A.nvox && lane == 0) {
+                A.fa_index[v] = act[vv] ? (double)best_fa[vv] : 0.0;
+                if (A.km) A.km[v] = act[vv] ? best_km[vv] : 0.0;
+            }
+            if (v < A.nvox && A.resid && !act[vv]) for (int f = lane; f < A.nfa; f += 64) A.resid[(size_t)v * A.nfa + f] = 0.0;
         }
         __syncthreads();
     }
@@ -460,7 +611,7 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
 __global__ __launch_bounds__(256) void finalize_unfitted_kernel(int64_t nvox, int n, int m, const int *__restrict__ key,
                                                                 const uint8_t *__restrict__ mask, double *__restrict__ fsol,
                                                                 double *__restrict__ sig, double *__restrict__ reg,
-                                                                double *__restrict__ maps)
+                                                                double *__restrict__ lam, double *__restrict__ maps)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -469,6 +620,7 @@ __global__ __launch_bounds__(256) void finalize_unfitted_kernel(int64_t nvox, in
     for (int64_t v = t0; v < nvox; v += stride) {
         if (key[v] >= 0) continue;
         reg[v] = 0.0;
+        if (lam) lam[v] = 0.0;
         if (maps) {
             bool mk = mask ? (mask[v] != 0) : true;
             maps[0 * nvox + v] = 0.0; maps[1 * nvox + v] = 0.0; maps[2 * nvox + v] = 0.0;
@@ -526,13 +678,33 @@ struct met2_plan {
     int nlam = 0;
     bool have_dict = false, have_pen = false, have_t2 = false;
     std::vector<double> Lhost;  // dense penalty as given
-    double logdetL = 0.0;
+    double log_detL = 0.0;      // log(det(L)) as bayesian_interpolation.py:100,123 uses it (-inf for L2)
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
     int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 };
+
+// determinant by LU with partial pivoting (scipy.linalg.det at bayesian_interpolation.py:100)
+static double det_lu(int n, const double *Ain)
+{
+    std::vector<double> A(Ain, Ain + (size_t)n * n);
+    double det = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int piv = c; double mx = fabs(A[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; ++r) if (fabs(A[(size_t)r * n + c]) > mx) { mx = fabs(A[(size_t)r * n + c]); piv = r; }
+        if (mx == 0.0) return 0.0;
+        if (piv != c) { for (int j = 0; j < n; ++j) std::swap(A[(size_t)c * n + j], A[(size_t)piv * n + j]); det = -det; }
+        double d = A[(size_t)c * n + c];
+        det *= d;
+        for (int r = c + 1; r < n; ++r) {
+            double l = A[(size_t)r * n + c] / d;
+            if (l != 0.0) for (int j = c + 1; j < n; ++j) A[(size_t)r * n + j] -= l * A[(size_t)c * n + j];
+        }
+    }
+    return det;
+}
 
 static void default_lambda_grid(std::vector<double> &g)
 {
@@ -563,15 +735,17 @@ static SortBufs sort_bufs(met2_plan *p)
     return sb;
 }
 
-struct LaunchGeom { int grid, block, waves, np, kmax, lds; };
+struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles; };
 
-static int fit_geometry(const met2_plan *p, LaunchGeom &g)
+static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
 {
     const int n = p->n_t2, m = p->n_te;
     g.np = n | 1;
     g.kmax = n;
+    g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
+    if (method == MET2_GCV && n * n > g.wave_doubles) g.wave_doubles = n * n;   // k x k support Gram for the Jacobi SVD
     const size_t shared = sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np);
-    const size_t per_wave = sizeof(double) * ((size_t)g.kmax * (g.kmax + 1) / 2);
+    const size_t per_wave = sizeof(double) * (size_t)g.wave_doubles;
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
     int w = (int)((budget - shared) / per_wave);
@@ -646,6 +820,21 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     default_lambda_grid(g);
     *out = p;
     return met2_plan_set_lambda_grid(p, g.data(), (int)g.size());
+}
+
+int met2_plan_set_options(met2_plan *p, const met2_options *opt)
+{
+    if (!p || !opt) return fail(MET2_E_INVALID, "NULL argument");
+    if (opt->device != p->opt.device) return fail(MET2_E_INVALID, "a plan cannot change device");
+    memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size);
+    return MET2_OK;
+}
+
+int met2_plan_get_options(met2_plan *p, met2_options *opt)
+{
+    if (!p || !opt) return fail(MET2_E_INVALID, "NULL argument");
+    *opt = p->opt;
+    return MET2_OK;
 }
 
 int met2_plan_destroy(met2_plan *p)
@@ -760,6 +949,7 @@ int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
     HIPCHK(hipMemcpy(p->dKband, kb.data(), sizeof(double) * 5 * 64, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->dLband, lb.data(), sizeof(double) * 5 * 64, hipMemcpyHostToDevice));
     p->Lhost.assign(L, L + (size_t)n * n);
+    p->log_detL = log(det_lu(n, L));
     p->have_pen = true;
     return MET2_OK;
 }
@@ -815,22 +1005,24 @@ int met2_plan_set_lambda_grid(met2_plan *p, const double *lam, int32_t n)
 }
 
 int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, const double *fa_index, const uint8_t *mask,
-             double *fsol, double *sig, double *reg, double *maps, int32_t *status, void *stream)
+             double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, void *stream)
 {
     if (!p || !data || !fsol || !reg) return fail(MET2_E_INVALID, "NULL argument");
     if (nvox < 0 || nvox > 0x7fffffff) return fail(MET2_E_INVALID, "nvox out of range");
     if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
     if (method != MET2_NNLS && !p->have_pen) return fail(MET2_E_STATE, "no penalty matrix set");
     if (maps && !p->have_t2) return fail(MET2_E_STATE, "metrics requested but no T2 grid set");
-    if (method == MET2_GCV || method == MET2_BAYESREG) return fail(MET2_E_UNSUPPORTED, "GCV/BayesReg kernels are not built yet");
+    const bool objgrid = method >= 10;
+    if (objgrid) { method -= 10; if (method != MET2_X2 && method != MET2_GCV && method != MET2_BAYESREG) return fail(MET2_E_INVALID, "no objective for this method"); }
     if (method < 0 || method > MET2_BAYESREG) return fail(MET2_E_INVALID, "unknown method");
+    if (objgrid && p->nlam > p->n_t2) return fail(MET2_E_UNSUPPORTED, "objective grid longer than n_t2");
     if (nvox == 0) return MET2_OK;
     HIPCHK(hipSetDevice(p->opt.device));
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_sort_bufs(p, nvox);
     if (rc) return rc;
     LaunchGeom g;
-    rc = fit_geometry(p, g);
+    rc = fit_geometry(p, method >= 10 ? method - 10 : method, g);
     if (rc) return rc;
     if (!p->have_pen) {   // plain NNLS never touches the bands, but the kernel loads them
         HIPCHK(hipMemsetAsync(p->dKband, 0, sizeof(double) * 5 * 64, s));
@@ -856,20 +1048,27 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     }
 
     FitArgs A;
-    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.chunk = chunk;
+    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.chunk = chunk; A.wave_doubles = g.wave_doubles;
     A.method = method; A.nlam = p->nlam;
     A.maxfun = p->opt.brent_maxfun > 0 ? p->opt.brent_maxfun : (method == MET2_BAYESREG ? 200 : 300);
     A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
     A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
+    A.log_detL = p->log_detL;
     A.Dfa = p->dD; A.Bfa = p->dB; A.kband = p->dKband; A.lband = p->dLband; A.lam_grid = p->dLam; A.t2s = p->dT2;
-    A.data = data; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.maps = maps; A.status = status; A.nvox = nvox;
+    A.data = data; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     HIPCHK(hipEventRecord(p->ev0, s));
-    switch (method) {
+    if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }
+    switch (objgrid ? method + 10 : method) {
+    case 10 + MET2_X2: rc = launch_fit<10 + MET2_X2>(A, g, s); break;
+    case 10 + MET2_GCV: rc = launch_fit<10 + MET2_GCV>(A, g, s); break;
+    case 10 + MET2_BAYESREG: rc = launch_fit<10 + MET2_BAYESREG>(A, g, s); break;
     case MET2_NNLS: rc = launch_fit<MET2_NNLS>(A, g, s); break;
     case MET2_T2SPARC: rc = launch_fit<MET2_T2SPARC>(A, g, s); break;
     case MET2_X2: rc = launch_fit<MET2_X2>(A, g, s); break;
     case MET2_LCURVE: rc = launch_fit<MET2_LCURVE>(A, g, s); break;
+    case MET2_GCV: rc = launch_fit<MET2_GCV>(A, g, s); break;
+    case MET2_BAYESREG: rc = launch_fit<MET2_BAYESREG>(A, g, s); break;
     default: rc = fail(MET2_E_UNSUPPORTED, "method not built");
     }
     if (rc) return rc;
@@ -885,7 +1084,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
         fflush(stderr);
     }
     hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
-                       sig, reg, maps);
+                       objgrid ? nullptr : sig, reg, objgrid ? nullptr : lam, objgrid ? nullptr : maps);
     HIPCHK(hipGetLastError());
     // FA index range errors are reported synchronously (they would be IndexError in the reference)
     int herr = 0;
@@ -898,8 +1097,27 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
 int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uint8_t *mask, double *fa_index, double *km,
                        double *resid, void *stream)
 {
-    (void)p; (void)nvox; (void)data; (void)mask; (void)fa_index; (void)km; (void)resid; (void)stream;
-    return fail(MET2_E_UNSUPPORTED, "brute-force FA kernel is not built yet");
+    if (!p || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
+    if (nvox <= 0) return MET2_OK;
+    HIPCHK(hipSetDevice(p->opt.device));
+    hipStream_t s = (hipStream_t)stream;
+    LaunchGeom g;
+    int rc = fit_geometry(p, MET2_NNLS, g);
+    if (rc) return rc;
+    SortBufs sb = sort_bufs(p);
+    HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
+    FaArgs A;
+    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
+    A.queue = sb.queue; A.nvox = nvox;
+    HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    HIPCHK(hipEventRecord(p->ev0, s));
+    hipLaunchKernelGGL(fa_kernel<4>, dim3(g.grid), dim3(g.block), g.lds, s, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(p->ev1, s));
+    p->timed = true;
+    return MET2_OK;
 }
 
 int met2_metrics(met2_plan *p, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps, void *stream)
@@ -930,10 +1148,9 @@ int met2_plan_last_kernel_ms(met2_plan *p, double *ms)
 
 int met2_plan_launch_info(met2_plan *p, int32_t method, int32_t *grid, int32_t *block, int32_t *lds_bytes)
 {
-    (void)method;
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
     LaunchGeom g;
-    int rc = fit_geometry(p, g);
+    int rc = fit_geometry(p, method, g);
     if (rc) return rc;
     if (grid) *grid = g.grid;
     if (block) *block = g.block;

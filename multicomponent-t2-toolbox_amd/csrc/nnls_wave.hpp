@@ -34,6 +34,7 @@ struct WaveShared {
     const double *sD;   // [m][np]
     double *R;          // this wave's packed factor
     int n, m, np, kmax;
+    int rcap;           // doubles available at R
 };
 
 // K = L^T L and L itself as 5 diagonals per lane: kb[d] = K[j][j+d-2], lb[d] = L[j][j+d-2]

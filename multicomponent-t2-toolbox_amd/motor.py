@@ -1,0 +1,112 @@
+"""Drop-ins for the voxel loop of motor/motor_recon_met2_real_data.py: create_Laplacian_matrix,
+fitting_slice_T2, and recon_met2_arrays -- the driver's steps 2-4 on in-memory arrays (NIfTI I/O,
+denoising, plots and the mean-spectrum diagnostics are out of scope)."""
+import math
+
+import numpy as np
+import torch
+
+from ._cache import plan_for
+from .plan import MAP_NAMES, Met2Plan
+
+
+def create_Laplacian_matrix(Npc, order):
+    """motor:86-111 -> dense [Npc, Npc]"""
+    L = np.zeros((Npc, Npc))
+    i = np.arange(Npc)
+    if order == 2:
+        L[i, i] = 2.0
+        L[i[1:], i[1:] - 1] = -1.0
+        L[i[:-1], i[:-1] + 1] = -1.0
+        L[0, 0] = 1.0
+        L[-1, -1] = 1.0
+    elif order == 1:
+        L[i, i] = 1.0
+        L[i[1:], i[1:] - 1] = -1.0
+    elif order == 0:
+        L[i, i] = 1.0
+    else:
+        raise ValueError("order must be 0, 1 or 2")
+    return L
+
+
+def create_InvT2_matrix(T2s):
+    """motor:263-269 (reg_matrix == 'InvT2')"""
+    T2s = np.asarray(T2s, dtype=np.float64)
+    d = T2s - np.concatenate(([T2s[0] - 1.0], T2s[:-1]))
+    d[0] = d[1]
+    return np.diag(1.0 / d)
+
+
+def penalty_matrix(reg_matrix, Npc, T2s=None):
+    """motor:254-273; unknown names raise (the reference calls sys.exit())."""
+    if reg_matrix == "I":
+        return create_Laplacian_matrix(Npc, 0)
+    if reg_matrix == "L1":
+        return create_Laplacian_matrix(Npc, 1)
+    if reg_matrix == "L2":
+        return create_Laplacian_matrix(Npc, 2)
+    if reg_matrix == "InvT2":
+        return create_InvT2_matrix(T2s)
+    raise ValueError("Error: Wrong reg_matrix option!")
+
+
+def fitting_slice_T2(mask_1d, data_1d, FA_index_1d, nx, Dic_3D, lambda_reg, T2dim, nEchoes, reg_method, Laplac, dist_x_prior=None):
+    """motor:113-162 -> (f_sol[nx, T2dim], signal[nx, nEchoes], reg[nx])"""
+    data = np.ascontiguousarray(data_1d, dtype=np.float64)
+    if not np.isfinite(data[np.asarray(mask_1d) > 0]).all():
+        raise ValueError("array must not contain infs or NaNs")     # algorithms.py:56
+    plan = plan_for(Dic_3D, Laplac, lambda_reg)
+    dev = plan.device
+    out = plan.fit(reg_method, torch.as_tensor(data, device=dev), fa_index=torch.as_tensor(np.asarray(FA_index_1d, dtype=np.float64), device=dev),
+                   mask=torch.as_tensor(np.asarray(mask_1d) > 0, device=dev), want_maps=False)
+    return out["fsol"].cpu().numpy(), out["sig"].cpu().numpy(), out["reg"].cpu().numpy()
+
+
+def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
+                      fa_index=None, device=0, plan=None):
+    """Steps 2-4 of motor_recon_met2 (motor:336-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
+    [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
+    negative values clipped to 0 (motor:279), Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms,
+    T1 = 1000 ms, 91 flip angles for brute force.  Returns a dict with the driver's ten outputs."""
+    if FA_method != "brute-force" and fa_index is None:
+        raise NotImplementedError("only FA_method='brute-force' (or a given fa_index) is built; 'spline' is SURVEY.md §8f item 1")
+    data = np.asarray(data, dtype=np.float64)
+    vol_shape = data.shape[:-1]
+    nt = data.shape[-1]
+    mask = np.asarray(mask).reshape(vol_shape)
+    d2 = (data * (mask[..., None] != 0)).reshape(-1, nt)
+    d2 = np.where(d2 < 0.0, 0.0, d2)
+    m1 = (mask.reshape(-1) > 0)
+    TE_array = np.asarray(TE_array, dtype=np.float64)
+    tau = float(TE_array[1] - TE_array[0])
+    Npc = 96 if reg_method == "T2SPARC" else 60
+    T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=Npc, endpoint=True, base=10.0)
+    T1s = 1000.0 * np.ones_like(T2s)
+    alpha_values = np.linspace(90.0, 180.0, 91)
+    own = plan is None
+    if own:
+        plan = Met2Plan(nt, Npc, 91, device=device, myelin_T2=myelin_T2)
+        plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
+        plan.set_penalty("InvT2" if reg_method == "T2SPARC" else reg_matrix, T2s)   # run_real_data_script.py:91-93
+    dev = plan.device
+    dd = torch.as_tensor(d2, device=dev)
+    mm = torch.as_tensor(m1, device=dev)
+    if fa_index is None:
+        fa, km, _ = plan.fa_bruteforce(dd, mm)
+    else:
+        fa = torch.as_tensor(np.asarray(fa_index, dtype=np.float64).reshape(-1), device=dev)
+    out = plan.fit(reg_method, dd, fa_index=fa, mask=mm)
+    res = {"fsol_4D": out["fsol"].cpu().numpy().reshape(vol_shape + (Npc,)),
+           "Est_Signal": out["sig"].cpu().numpy().reshape(vol_shape + (nt,)),
+           "reg_param": out["reg"].cpu().numpy().reshape(vol_shape),
+           "FA_index": fa.cpu().numpy().reshape(vol_shape)}
+    fitted_fa = (m1 & (d2.sum(axis=1) > 0)).reshape(vol_shape)
+    res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
+    maps = out["maps"].cpu().numpy()
+    for i, name in enumerate(MAP_NAMES):
+        res[name] = maps[i].reshape(vol_shape)
+    res["T2s"] = T2s
+    if own:
+        plan.close()
+    return res

@@ -54,6 +54,17 @@ class Met2Plan:
             pass
 
     # ---- configuration
+    def set_options(self, **kw):
+        """x2_factor, t2sparc_lambda, brent_xtol, brent_maxfun, t2_myelin_cut, t2_ie_cut"""
+        opt = Options()
+        check(lib().met2_plan_get_options(self._h, C.byref(opt)))
+        for k, v in kw.items():
+            if not hasattr(opt, k):
+                raise AttributeError(k)
+            setattr(opt, k, v)
+        check(lib().met2_plan_set_options(self._h, C.byref(opt)))
+        return self
+
     def build_dictionary_epg(self, T2s, T1s, tau, alpha_values, TR):
         (_, p2), (_, p1), (_, pa) = _h(T2s), _h(T1s), _h(alpha_values)
         keep = (_h(T2s), _h(T1s), _h(alpha_values))
@@ -100,7 +111,8 @@ class Met2Plan:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- hot path (device tensors in, device tensors out)
-    def fit(self, method, data, fa_index=None, mask=None, want_sig=True, want_maps=True, want_status=True, out=None):
+    def fit(self, method, data, fa_index=None, mask=None, want_sig=True, want_maps=True, want_status=True, want_lambda=False,
+            out=None):
         """data [nvox, n_te] float64 cuda tensor.  Returns dict of cuda tensors."""
         assert data.is_cuda and data.dtype == torch.float64 and data.dim() == 2 and data.shape[1] == self.n_te
         data = data.contiguous()
@@ -114,12 +126,28 @@ class Met2Plan:
         fsol = o.get("fsol") if "fsol" in o else torch.empty((nvox, self.n_t2), dtype=torch.float64, device=dev)
         sig = (o.get("sig") if "sig" in o else torch.empty((nvox, self.n_te), dtype=torch.float64, device=dev)) if want_sig else None
         reg = o.get("reg") if "reg" in o else torch.empty((nvox,), dtype=torch.float64, device=dev)
+        lam = (o.get("lam") if "lam" in o else torch.empty((nvox,), dtype=torch.float64, device=dev)) if want_lambda else None
         maps = (o.get("maps") if "maps" in o else torch.empty((6, nvox), dtype=torch.float64, device=dev)) if want_maps else None
         status = (o.get("status") if "status" in o else torch.empty((nvox,), dtype=torch.int32, device=dev)) if want_status else None
         with torch.cuda.device(dev):
             check(lib().met2_fit(self._h, METHODS[method], nvox, _ptr(data), _ptr(fa_index), _ptr(mask), _ptr(fsol), _ptr(sig),
-                                 _ptr(reg), _ptr(maps), _ptr(status), self._stream()))
-        return {"fsol": fsol, "sig": sig, "reg": reg, "maps": maps, "status": status}
+                                 _ptr(reg), _ptr(lam), _ptr(maps), _ptr(status), self._stream()))
+        return {"fsol": fsol, "sig": sig, "reg": reg, "lam": lam, "maps": maps, "status": status}
+
+    def objective_grid(self, method, data, lams, fa_index=None):
+        """Values of `method`'s lambda-selection objective at `lams` for every voxel -> [nvox, len(lams)]."""
+        lams = np.ascontiguousarray(lams, dtype=np.float64)
+        assert 3 <= lams.shape[0] <= self.n_t2
+        self.set_lambda_grid(lams)
+        data = data.contiguous()
+        nvox = data.shape[0]
+        fsol = torch.empty((nvox, self.n_t2), dtype=torch.float64, device=data.device)
+        reg = torch.empty((nvox,), dtype=torch.float64, device=data.device)
+        fa = None if fa_index is None else fa_index.to(device=data.device, dtype=torch.float64).contiguous()
+        with torch.cuda.device(data.device):
+            check(lib().met2_fit(self._h, 10 + METHODS[method], nvox, _ptr(data), _ptr(fa), _ptr(None), _ptr(fsol), _ptr(None),
+                                 _ptr(reg), _ptr(None), _ptr(None), _ptr(None), self._stream()))
+        return fsol[:, : lams.shape[0]]
 
     def fa_bruteforce(self, data, mask=None, want_resid=False):
         assert data.is_cuda and data.dtype == torch.float64 and data.shape[1] == self.n_te

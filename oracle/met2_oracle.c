@@ -566,7 +566,7 @@ static void o_jacobi_svd(int k, double *A /* in: matrix cols; out: U*s (col-majo
                 double *ap = A + (size_t)p * k, *aq = A + (size_t)q * k;
                 double alpha = 0, beta = 0, gamma = 0;
                 for (int i = 0; i < k; ++i) { alpha += ap[i] * ap[i]; beta += aq[i] * aq[i]; gamma += ap[i] * aq[i]; }
-                if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
                 rotated = 1;
                 double zeta = (beta - alpha) / (2.0 * gamma);
                 double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
