@@ -41,7 +41,7 @@ def host_cores():
     return int(os.environ.get("MET2_CPU_THREADS", n))
 
 
-def cpu_baseline(method, pen, data_cpu, nte, nt2, T2s, T1s, alphas, seconds=15.0):
+def cpu_baseline(method, pen, data_cpu, nte, nt2, T2s, T1s, alphas, lam_grid, seconds=15.0):
     """The oracle ("port": the C restatement in oracle/) timed on this host's cores on a bounded
     sample of the same voxels.  Checker code used as a reported baseline only."""
     from oracle import oracle
@@ -51,11 +51,11 @@ def cpu_baseline(method, pen, data_cpu, nte, nt2, T2s, T1s, alphas, seconds=15.0
     L = oracle.penalty(nt2, pen, T2s)
     n0 = min(256 * cores, data_cpu.shape[0])
     t = time.time()
-    oracle.fit_batch(method, D, L, data_cpu[:n0], np.zeros(n0), np.ones(n0), nthreads=cores)
+    oracle.fit_batch(method, D, L, data_cpu[:n0], np.zeros(n0), np.ones(n0), lambda_reg=lam_grid, nthreads=cores)
     rate = n0 / max(time.time() - t, 1e-6)
     n1 = int(min(data_cpu.shape[0], max(n0, rate * seconds)))
     t = time.time()
-    fs, sg, rg, st = oracle.fit_batch(method, D, L, data_cpu[:n1], np.zeros(n1), np.ones(n1), nthreads=cores)
+    fs, sg, rg, st = oracle.fit_batch(method, D, L, data_cpu[:n1], np.zeros(n1), np.ones(n1), lambda_reg=lam_grid, nthreads=cores)
     dt = time.time() - t
     return {"value": n1 / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
             "sample": "first %d voxels of the same volume, %s/%s, %.1f s, OpenMP over voxels" % (n1, method, pen, dt)}, (fs, n1)
@@ -161,7 +161,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             cb, (fs_ref, n1) = cpu_baseline(args.method, args.penalty, data[: min(nvox, 1 << 17)].cpu().numpy(), nte, nt2, T2s, T1s,
-                                            alphas, seconds=args.cpu_seconds)
+                                            alphas, synth.lambda_grid(), seconds=args.cpu_seconds)
             line["cpu_baseline"] = cb
             got = out["fsol"][:n1].cpu().numpy()
             den = np.max(np.abs(fs_ref), axis=1); den[den == 0] = 1.0
