@@ -376,6 +376,7 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
             const double km = bcast(b, 0);
             b = b / km;
             NnlsState st; st.itmax_hit = 0;
+            nnls_reset(st);
             {
                 double h = 0.0;
                 for (int e = 0; e < m; ++e) {
@@ -399,12 +400,12 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 const double target = A.x2_factor * SSE;
                 int flag;
                 double lam = fminbound_dev([&](double x) {
-                    nnls_solve(S, bd, st, x, true, lane);
+                    nnls_solve_warm(S, bd, st, x, true, lane);
                     double SSEr = sse_of(S, st, b, lane);
                     return fabs(SSEr - target) / SSE;
                 }, 0.0, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                nnls_solve(S, bd, st, lam, true, lane);
+                nnls_solve_warm(S, bd, st, lam, true, lane);
                 regv = sse_of(S, st, b, lane) / SSE;          // k_est (motor:141-143)
                 lamv = lam;
             } else if (METHOD == MET2_LCURVE) {
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 double le = 0.0, ln = 0.0;
                 for (int i = 0; i < A.nlam; ++i) {
                     double lam = A.lam_grid[i];
-                    nnls_solve(S, bd, st, lam, true, lane);
+                    nnls_solve_warm(S, bd, st, lam, true, lane);
                     double sse = sse_of(S, st, b, lane);
                     double lf = band_mul(bd.lb, st.x, lane);
                     lf = (lane < n) ? lf : 0.0;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 }
                 int corner = select_corner_dev(le, ln, A.nlam, lane);
                 regv = lamv = A.lam_grid[corner];
-                nnls_solve(S, bd, st, regv, true, lane);
+                nnls_solve_warm(S, bd, st, regv, true, lane);
             } else if (METHOD == MET2_BAYESREG) {
                 // bayesian_interpolation.py:84-105
                 nnls_solve(S, bd, st, 0.0, false, lane);
@@ -431,23 +432,23 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
                 int flag;
                 double lam = fminbound_dev([&](double x) {
-                    nnls_solve(S, bd, st, x, true, lane);
+                    nnls_solve_warm(S, bd, st, x, true, lane);
                     return bayes_objective(S, bd, st, bc, x, b, lane);
                 }, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
-                nnls_solve(S, bd, st, lam, true, lane);
+                nnls_solve_warm(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
                 int flag, overflow = 0;
                 double lam = fminbound_dev([&](double x) {
-                    nnls_solve(S, bd, st, x, true, lane);
+                    nnls_solve_warm(S, bd, st, x, true, lane);
                     return gcv_objective(S, bd, st, x, b, lane, overflow);
                 }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
-                nnls_solve(S, bd, st, lam, true, lane);
+                nnls_solve_warm(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             }
             if (METHOD >= 10) {

@@ -97,16 +97,15 @@ __device__ __forceinline__ double back_subst(const WaveShared &S, const NnlsStat
 {
     const int k = st.k;
     const int rbl = row_base(lane, S.kmax);
-    double y = st.y, z = 0.0;
+    double y = st.y;
     double rv = (k > 0 && lane < k - 1) ? S.R[rbl + (k - 1)] : 0.0;
     for (int c = k - 1; c >= 0; --c) {
         double rvn = (c > 0 && lane < c - 1) ? S.R[rbl + (c - 1)] : 0.0;   // prefetch next column
         double s = bcast(y * st.rinv, c);
-        z = (lane == c) ? s : z;
-        y = fma(-rv, s, y);
+        y = fma(-rv, s, y);                                                 // lanes >= c are final (rv = 0 there)
         rv = rvn;
     }
-    return z;
+    return (lane < k) ? y * st.rinv : 0.0;
 }
 
 // Remove position p from the passive set: delete column p of R and re-triangularise.
@@ -155,7 +154,8 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState &st, i
 // Try to move bin t from Z to P.  Returns false (state untouched) when the column is
 // numerically dependent on the passive columns or its trial coefficient is not
 // positive (Lawson-Hanson's two acceptance tests).
-__device__ __forceinline__ bool try_append(const WaveShared &S, const Band &bd, NnlsState &st, double lam, int t, int lane)
+__device__ __forceinline__ bool try_append(const WaveShared &S, const Band &bd, NnlsState &st, double lam, int t, int lane,
+                                           bool forced = false)
 {
     const int k = st.k, kmax = S.kmax;
     double gb = (lane < S.n) ? S.sB[t * S.np + lane] : 0.0;
@@ -164,25 +164,23 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band &bd, 
     double g = gather(gb, st.ord);                               // position-indexed G[ord_p][t]
     g = (lane < k) ? g : 0.0;
     // forward substitution R^T r = g
-    double r = 0.0;
     {
         double rv = (k > 0 && lane > 0 && lane < k) ? S.R[row_base(0, kmax) + lane] : 0.0;
         for (int i = 0; i < k; ++i) {
             double rvn = (i + 1 < k && lane > i + 1 && lane < k) ? S.R[row_base(i + 1, kmax) + lane] : 0.0;
             double s = bcast(g * st.rinv, i);
-            r = (lane == i) ? s : r;
-            g = fma(-rv, s, g);
+            g = fma(-rv, s, g);                                  // lanes <= i are final (rv = 0 there)
             rv = rvn;
         }
     }
+    const double r = (lane < k) ? g * st.rinv : 0.0;
     double rr = r * r, ry = r * st.y;       // both zero for lanes >= k
-    rr = (lane < k) ? rr : 0.0; ry = (lane < k) ? ry : 0.0;
     wave_sum2(rr, ry);
     const double rho2 = gtt - rr;
     if (!(rho2 > 1e-14 * gtt)) return false;                     // dependent column (noise floor of gtt - r.r)
     const double rho = sqrt(rho2);
     const double ynew = (bcast(st.h, t) - ry) / rho;
-    if (!(ynew / rho > 0.0)) return false;                       // ztest
+    if (!forced && !(ynew / rho > 0.0)) return false;            // ztest
     if (lane < k) S.R[row_base(lane, kmax) + k] = r;
     if (lane == k) { S.R[row_base(k, kmax) + k] = rho; st.rinv = 1.0 / rho; st.y = ynew; st.ord = t; }
     __builtin_amdgcn_wave_barrier();
@@ -208,12 +206,46 @@ __device__ __forceinline__ double dual(const WaveShared &S, const Band &bd, cons
     return w;
 }
 
-// Passive-set iterations from the current state (x feasible, R/y consistent with P at lam)
-// until the KKT conditions hold.  mrows = number of rows of the (augmented) system.
-__device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd, NnlsState &st, double lam, int mrows, int lane)
+// Lawson-Hanson's secondary loop: from a feasible x and a factor consistent with (P, lambda), move to
+// the solution of the passive sub-problem, dropping variables that hit zero on the way.
+// Returns false when the iteration cap is reached.
+__device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState &st, int &iter, int itmax, int lane)
+{
+    for (;;) {
+        if (++iter > itmax) return false;
+        double z = back_subst(S, st, lane);                 // position-indexed
+        double xp = gather(st.x, st.ord);                   // x at position
+        bool neg = (lane < st.k) && (z <= 0.0);
+        u64 negm = ballot(neg);
+        double zb = gather(z, st.pos < 0 ? 0 : st.pos);     // bin-indexed
+        zb = (st.pos >= 0) ? zb : 0.0;
+        if (!negm) { st.x = zb; return true; }
+        double ratio = neg ? xp / (xp - z) : 2.0;
+        ratio = (ratio == ratio) ? ratio : 2.0;             // 0/0: Lawson-Hanson's `alpha > t` is false for NaN
+        double alpha = wave_min(ratio);
+        if (!(alpha < 2.0)) { st.x = zb; return true; }     // "alpha still 2": accept z
+        int jj = first_lane(ballot(neg && ratio == alpha));
+        st.x = (st.pos >= 0) ? fma(alpha, zb - st.x, st.x) : 0.0;
+        remove_pos(S, st, jj, lane);
+        for (int sweep = 0; sweep < 64; ++sweep) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
+            double xq = gather(st.x, st.ord);
+            u64 bad = ballot((lane < st.k) && (xq <= 0.0));
+            if (!bad) break;
+            MET2_STAT(1, sweep + 1);
+            remove_pos(S, st, first_lane(bad), lane);
+        }
+    }
+}
+
+// Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
+// warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
+// (P, lam) -- start with the secondary loop instead of from the empty set.
+__device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd, NnlsState &st, double lam, int mrows, int lane,
+                                             bool warm = false)
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
+    if (warm && st.k > 0 && !nnls_inner(S, st, iter, itmax, lane)) { st.itmax_hit = 1; return; }
     for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows || st.k >= S.kmax) break;
         double w = dual(S, bd, st, lam, lane);
@@ -231,33 +263,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd
             MET2_STAT(0, tries + 1);
         }
         if (!accepted) break;
-        // secondary loop
-        bool capped = false;
-        for (;;) {
-            if (++iter > itmax) { capped = true; break; }
-            double z = back_subst(S, st, lane);                 // position-indexed
-            double xp = gather(st.x, st.ord);                   // x at position
-            bool neg = (lane < st.k) && (z <= 0.0);
-            u64 negm = ballot(neg);
-            double zb = gather(z, st.pos < 0 ? 0 : st.pos);     // bin-indexed
-            zb = (st.pos >= 0) ? zb : 0.0;
-            if (!negm) { st.x = zb; break; }
-            double ratio = neg ? xp / (xp - z) : 2.0;
-            ratio = (ratio == ratio) ? ratio : 2.0;             // 0/0: Lawson-Hanson's `alpha > t` is false for NaN
-            double alpha = wave_min(ratio);
-            if (!(alpha < 2.0)) { st.x = zb; break; }           // "alpha still 2": accept z
-            int jj = first_lane(ballot(neg && ratio == alpha));
-            st.x = (st.pos >= 0) ? fma(alpha, zb - st.x, st.x) : 0.0;
-            remove_pos(S, st, jj, lane);
-            for (int sweep = 0; sweep < 64; ++sweep) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
-                double xq = gather(st.x, st.ord);
-                u64 bad = ballot((lane < st.k) && (xq <= 0.0));
-                if (!bad) break;
-                MET2_STAT(1, sweep + 1);
-                remove_pos(S, st, first_lane(bad), lane);
-            }
-        }
-        if (capped) { st.itmax_hit = 1; break; }
+        if (!nnls_inner(S, st, iter, itmax, lane)) { st.itmax_hit = 1; break; }
         MET2_STAT(2, outer + 1);
         MET2_STAT(3, iter);
     }
@@ -273,6 +279,22 @@ __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band &bd, 
 {
     nnls_reset(st);
     nnls_iterate(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
+}
+
+// Warm start: keep the previous solution's passive set and x (a feasible point for any lambda),
+// rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
+// strictly convex problem does not depend on the starting point, so this returns the same x as the
+// cold start up to rounding; it only skips the passes that would rebuild the same passive set.
+__device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band &bd, NnlsState &st, double lam, bool aug, int lane)
+{
+    const int kold = st.k, ordold = st.ord;
+    if (kold == 0) { nnls_solve(S, bd, st, lam, aug, lane); return; }
+    st.k = 0; st.P = 0ull; st.pos = -1;
+    for (int p = 0; p < kold; ++p) {
+        const int t = bcast_i(ordold, p);
+        if (!try_append(S, bd, st, lam, t, lane, true) && lane == t) st.x = 0.0;   // column became dependent: drop it
+    }
+    nnls_iterate(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
 }
 
 // D x  (lane e < m holds (D x)_e), using the passive set of st
