@@ -319,28 +319,93 @@ __device__ __forceinline__ int select_corner_dev(double le, double ln, int nl, i
     return first_lane(ballot(tie && (double)bestk == kmin));
 }
 
-template <int METHOD>
+// Per-lane constants of the metrics windows (motor:221-224, 444)
+template <int NB>
+struct MetricLanes {
+    double logt2[NB];
+    bool isM[NB], isIE[NB], isCSF[NB];
+};
+
+template <int NB>
+__device__ __forceinline__ void metric_lanes(MetricLanes<NB> &ml, const double *t2s, int n, double cut_m, double cut_ie, int lane)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = lane + 64 * b;
+        const double t2 = (j < n) ? t2s[j] : 1.0;
+        ml.logt2[b] = (j < n) ? log(t2) : 0.0;
+        ml.isM[b] = (j < n) && (t2 <= cut_m);
+        ml.isIE[b] = (j < n) && (t2 > cut_m) && (t2 <= cut_ie);
+        ml.isCSF[b] = (j < n) && (t2 >= cut_ie);
+    }
+}
+
+// motor:448-468 for one voxel held bin-indexed in xs (already un-normalised); lane 0 writes the six maps
+template <int NB>
+__device__ __forceinline__ void write_metrics(const MetricLanes<NB> &ml, const double (&xs)[NB], bool mk, double *maps, int64_t nvox,
+                                              int64_t v, int lane)
+{
+    const double epsilon = 1.0e-16;
+    double tot = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) tot += xs[b];
+    const double vt = wave_sum(tot) + epsilon;
+    double fm = 0.0, fie = 0.0, fcsf = 0.0, lm = 0.0, lie = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double xn = xs[b] / vt;
+        fm += ml.isM[b] ? xn : 0.0;
+        fie += ml.isIE[b] ? xn : 0.0;
+        fcsf += ml.isCSF[b] ? xn : 0.0;
+        lm += ml.isM[b] ? xn * ml.logt2[b] : 0.0;
+        lie += ml.isIE[b] ? xn * ml.logt2[b] : 0.0;
+    }
+    fcsf = wave_sum(fcsf);
+    wave_sum2(fm, fie);
+    wave_sum2(lm, lie);
+    if (lane == 0) {
+        maps[0 * nvox + v] = mk ? fm : 0.0;
+        maps[1 * nvox + v] = mk ? fie : 0.0;
+        maps[2 * nvox + v] = mk ? fcsf : 0.0;
+        maps[3 * nvox + v] = mk ? exp(lm / (fm + epsilon)) : 0.0;
+        maps[4 * nvox + v] = mk ? exp(lie / (fie + epsilon)) : 0.0;
+        maps[5 * nvox + v] = mk ? vt : 0.0;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, const double *lband, int lane)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) { bd.kb[b][d] = kband[d * 128 + lane + 64 * b]; bd.lb[b][d] = lband[d * 128 + lane + 64 * b]; }
+}
+
+// METHOD: met2_method, or 10 + method for the objective-grid diagnostic.  NB: T2 bins per lane.
+// NB == 1: D and B of the workgroup's flip angle are staged in LDS; NB == 2: read from L2.
+template <int METHOD, int NB>
 __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, np = A.np, kmax = A.kmax;
     const int tri = A.wave_doubles;
+    constexpr bool STAGE = (NB == 1);
     double *sB = smem;
-    double *sD = sB + n * np;
-    double *sR = sD + m * np + (size_t)wave * tri;
-    int *sI = (int *)(sD + m * np + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
+    double *sD = sB + (STAGE ? n * np : 0);
+    double *sR0 = sD + (STAGE ? m * np : 0);
+    double *sR = sR0 + (size_t)wave * tri;
+    int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.sB = sB; S.sD = sD; S.R = sR; S.n = n; S.m = m; S.np = np; S.kmax = kmax; S.rcap = tri;
-    Band bd;
-#pragma unroll
-    for (int d = 0; d < 5; ++d) { bd.kb[d] = A.kband[d * 64 + lane]; bd.lb[d] = A.lband[d * 64 + lane]; }
-    const double t2 = (lane < n) ? A.t2s[lane] : 0.0;
-    const double logt2 = (lane < n) ? log(t2) : 0.0;
-    const bool isM = (lane < n) && (t2 <= A.cut_m);
-    const bool isIE = (lane < n) && (t2 > A.cut_m) && (t2 <= A.cut_ie);
-    const bool isCSF = (lane < n) && (t2 >= A.cut_ie);
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri;
+    if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
+    else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
+    Band<NB> bd;
+    load_band<NB>(bd, A.kband, A.lband, lane);
+    MetricLanes<NB> ml;
+    metric_lanes<NB>(ml, A.t2s, n, A.cut_m, A.cut_ie, lane);
 
     const int nchunks = A.sb.chunk_start[A.nfa];
     int loaded_fa = -1;
@@ -355,14 +420,16 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
         const int fa = lo;
         const int first = A.sb.bucket_start[fa] + (c - A.sb.chunk_start[fa]) * A.chunk;
         const int cnt = min(A.chunk, A.sb.bucket_start[fa + 1] - first);
-        if (fa != loaded_fa) {
-            const double *Bf = A.Bfa + (size_t)fa * n * n;
-            const double *Df = A.Dfa + (size_t)fa * m * n;
-            for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
-            for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
-            loaded_fa = fa;
-            __syncthreads();
-        }
+        const double *Bf = A.Bfa + (size_t)fa * n * n;
+        const double *Df = A.Dfa + (size_t)fa * m * n;
+        if (STAGE) {
+            if (fa != loaded_fa) {
+                for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
+                for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
+                loaded_fa = fa;
+                __syncthreads();
+            }
+        } else { S.B = Bf; S.D = Df; }
         for (int taken = 0; taken <= cnt; ++taken) {
             int slot = 0;
             if (lane == 0) slot = atomicAdd(&sI[1], 1);
@@ -375,80 +442,72 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
             double b = (lane < m) ? A.data[(size_t)v * m + lane] : 0.0;
             const double km = bcast(b, 0);
             b = b / km;
-            NnlsState st; st.itmax_hit = 0;
-            nnls_reset(st);
-            {
-                double h = 0.0;
-                for (int e = 0; e < m; ++e) {
-                    double be = bcast(b, e);
-                    double dv = (lane < n) ? sD[e * np + lane] : 0.0;
-                    h = fma(dv, be, h);
-                }
-                st.h = h;
-            }
+            NnlsState<NB> st; st.itmax_hit = 0;
+            nnls_reset<NB>(st);
+            project<NB>(S, b, lane, st.h);
             double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
 
             if (METHOD == MET2_NNLS) {
-                nnls_solve(S, bd, st, 0.0, false, lane);
+                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
             } else if (METHOD == MET2_T2SPARC) {
-                nnls_solve(S, bd, st, A.t2sparc_lambda, true, lane);
+                nnls_solve<NB>(S, bd, st, A.t2sparc_lambda, true, lane);
                 regv = lamv = A.t2sparc_lambda;
             } else if (METHOD == MET2_X2) {
                 // algorithms.py:211-233
-                nnls_solve(S, bd, st, 0.0, false, lane);
-                const double SSE = sse_of(S, st, b, lane);
+                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+                const double SSE = sse_of<NB>(S, st, b, lane);
                 const double target = A.x2_factor * SSE;
                 int flag;
                 double lam = fminbound_dev([&](double x) {
-                    nnls_solve_warm(S, bd, st, x, true, lane);
-                    double SSEr = sse_of(S, st, b, lane);
+                    nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    double SSEr = sse_of<NB>(S, st, b, lane);
                     return fabs(SSEr - target) / SSE;
                 }, 0.0, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                nnls_solve_warm(S, bd, st, lam, true, lane);
-                regv = sse_of(S, st, b, lane) / SSE;          // k_est (motor:141-143)
+                nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                regv = sse_of<NB>(S, st, b, lane) / SSE;          // k_est (motor:141-143)
                 lamv = lam;
             } else if (METHOD == MET2_LCURVE) {
                 // algorithms.py:88-113
                 double le = 0.0, ln = 0.0;
                 for (int i = 0; i < A.nlam; ++i) {
                     double lam = A.lam_grid[i];
-                    nnls_solve_warm(S, bd, st, lam, true, lane);
-                    double sse = sse_of(S, st, b, lane);
-                    double lf = band_mul(bd.lb, st.x, lane);
-                    lf = (lane < n) ? lf : 0.0;
-                    double sn = wave_sum(lf * lf);
+                    nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                    double sse = sse_of<NB>(S, st, b, lane);
+                    double sn = seminorm2<NB>(bd, st.x, n, lane);
                     if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
                 }
                 int corner = select_corner_dev(le, ln, A.nlam, lane);
                 regv = lamv = A.lam_grid[corner];
-                nnls_solve_warm(S, bd, st, regv, true, lane);
+                nnls_solve_warm<NB>(S, bd, st, regv, true, lane);
             } else if (METHOD == MET2_BAYESREG) {
                 // bayesian_interpolation.py:84-105
-                nnls_solve(S, bd, st, 0.0, false, lane);
-                const int nnz = __popcll(ballot((lane < n) && (st.x > 0.0)));
+                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+                int nnz = 0;
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) nnz += __popcll(ballot((lane + 64 * bb < n) && (st.x[bb] > 0.0)));
                 double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
-                const double sigma = sqrt(sse_of(S, st, b, lane) / dof);
+                const double sigma = sqrt(sse_of<NB>(S, st, b, lane) / dof);
                 BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
                 int flag;
                 double lam = fminbound_dev([&](double x) {
-                    nnls_solve_warm(S, bd, st, x, true, lane);
-                    return bayes_objective(S, bd, st, bc, x, b, lane);
+                    nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    return bayes_objective<NB>(S, bd, st, bc, x, b, lane);
                 }, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
-                nnls_solve_warm(S, bd, st, lam, true, lane);
+                nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
                 int flag, overflow = 0;
                 double lam = fminbound_dev([&](double x) {
-                    nnls_solve_warm(S, bd, st, x, true, lane);
-                    return gcv_objective(S, bd, st, x, b, lane, overflow);
+                    nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    return gcv_objective<NB>(S, bd, st, x, b, lane, overflow);
                 }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
-                nnls_solve_warm(S, bd, st, lam, true, lane);
+                nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             }
             if (METHOD >= 10) {
@@ -456,9 +515,11 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 constexpr int BASE = METHOD - 10;
                 double SSE = 1.0; BayesCtx bc; bc.failed = 0; bc.log_detL = A.log_detL; bc.beta = 1.0;
                 if (BASE == MET2_X2 || BASE == MET2_BAYESREG) {
-                    nnls_solve(S, bd, st, 0.0, false, lane);
-                    SSE = sse_of(S, st, b, lane);
-                    const int nnz = __popcll(ballot((lane < n) && (st.x > 0.0)));
+                    nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+                    SSE = sse_of<NB>(S, st, b, lane);
+                    int nnz = 0;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) nnz += __popcll(ballot((lane + 64 * bb < n) && (st.x[bb] > 0.0)));
                     double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
                     const double sigma = sqrt(SSE / dof);
                     bc.beta = 1.0 / (sigma * sigma);
@@ -466,44 +527,32 @@ __global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
                 double keep = 0.0; int overflow = 0;
                 for (int i = 0; i < A.nlam; ++i) {
                     const double x = A.lam_grid[i];
-                    nnls_solve(S, bd, st, x, true, lane);
+                    nnls_solve<NB>(S, bd, st, x, true, lane);
                     double val;
-                    if (BASE == MET2_X2) val = fabs(sse_of(S, st, b, lane) - A.x2_factor * SSE) / SSE;
-                    else if (BASE == MET2_GCV) val = gcv_objective(S, bd, st, x, b, lane, overflow);
-                    else val = bayes_objective(S, bd, st, bc, x, b, lane);
+                    if (BASE == MET2_X2) val = fabs(sse_of<NB>(S, st, b, lane) - A.x2_factor * SSE) / SSE;
+                    else if (BASE == MET2_GCV) val = gcv_objective<NB>(S, bd, st, x, b, lane, overflow);
+                    else val = bayes_objective<NB>(S, bd, st, bc, x, b, lane);
                     if (lane == i) keep = val;
                 }
-                if (lane < n) A.fsol[(size_t)v * n + lane] = keep;
+                if (lane < n) A.fsol[(size_t)v * n + lane] = keep;      // nlam <= 64 values, zero-padded to n
+                if (NB == 2 && lane + 64 < n) A.fsol[(size_t)v * n + lane + 64] = 0.0;
                 if (lane == 0) { A.reg[v] = 0.0; if (A.status) A.status[v] = stat | (overflow ? MET2_ST_KOVERFLOW : 0); }
                 continue;
             }
             if (st.itmax_hit) stat |= MET2_ST_ITMAX;
 
             // ---- epilogue: un-normalise (motor:153-155) + metrics (motor:448-468)
-            const double xs = st.x * km;
-            if (lane < n) A.fsol[(size_t)v * n + lane] = xs;
+            double xs[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                xs[bb] = st.x[bb] * km;
+                if (lane + 64 * bb < n) A.fsol[(size_t)v * n + lane + 64 * bb] = xs[bb]; else xs[bb] = 0.0;
+            }
             if (A.sig) {
-                double sg = model_signal(S, st, lane) * km;
+                double sg = model_signal<NB>(S, st, lane) * km;
                 if (lane < m) A.sig[(size_t)v * m + lane] = sg;
             }
-            if (A.maps) {
-                const double epsilon = 1.0e-16;
-                double vt = wave_sum(lane < n ? xs : 0.0) + epsilon;
-                double xn = xs / vt;
-                double fm = isM ? xn : 0.0, fie = isIE ? xn : 0.0;
-                double lm = isM ? xn * logt2 : 0.0, lie = isIE ? xn * logt2 : 0.0;
-                double fcsf = wave_sum(isCSF ? xn : 0.0);
-                wave_sum2(fm, fie);
-                wave_sum2(lm, lie);
-                if (lane == 0) {
-                    A.maps[0 * A.nvox + v] = fm;
-                    A.maps[1 * A.nvox + v] = fie;
-                    A.maps[2 * A.nvox + v] = fcsf;
-                    A.maps[3 * A.nvox + v] = exp(lm / (fm + epsilon));
-                    A.maps[4 * A.nvox + v] = exp(lie / (fie + epsilon));
-                    A.maps[5 * A.nvox + v] = vt;
-                }
-            }
+            if (A.maps) write_metrics<NB>(ml, xs, true, A.maps, A.nvox, v, lane);
             if (lane == 0) {
                 A.reg[v] = regv;
                 if (A.lam) A.lam[v] = lamv;
@@ -530,21 +579,27 @@ struct FaArgs {
     int64_t nvox;
 };
 
-template <int VPW>
+template <int VPW, int NB>
 __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, np = A.np;
+    constexpr bool STAGE = (NB == 1);
     double *sB = smem;
-    double *sD = sB + n * np;
-    double *sR = sD + m * np + (size_t)wave * A.wave_doubles;
-    int *sI = (int *)(sD + m * np + (size_t)A.waves * A.wave_doubles);
+    double *sD = sB + (STAGE ? n * np : 0);
+    double *sR0 = sD + (STAGE ? m * np : 0);
+    double *sR = sR0 + (size_t)wave * A.wave_doubles;
+    int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
-    S.sB = sB; S.sD = sD; S.R = sR; S.n = n; S.m = m; S.np = np; S.kmax = A.kmax; S.rcap = A.wave_doubles;
-    Band bd;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles;
+    if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
+    else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
+    Band<NB> bd;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) { bd.kb[d] = 0.0; bd.lb[d] = 0.0; }
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) { bd.kb[b][d] = 0.0; bd.lb[b][d] = 0.0; }
     const int tile_vox = A.waves * VPW;
     const int64_t ntiles = (A.nvox + tile_vox - 1) / tile_vox;
     for (int64_t round = 0; round <= ntiles; ++round) {
@@ -568,29 +623,28 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
             best_r[vv] = INFINITY; best_km[vv] = 0.0; best_fa[vv] = 0;
         }
         for (int fa = 0; fa < A.nfa; ++fa) {
-            __syncthreads();
             const double *Bf = A.Bfa + (size_t)fa * n * n;
             const double *Df = A.Dfa + (size_t)fa * m * n;
-            for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
-            for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
-            __syncthreads();
+            if (STAGE) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
+                for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
+                __syncthreads();
+            } else { S.B = Bf; S.D = Df; }
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
                 if (!act[vv]) continue;
-                NnlsState st; st.itmax_hit = 0;
-                double h = 0.0;
-                for (int e = 0; e < m; ++e) {
-                    double be = bcast(b[vv], e);
-                    double dv = (lane < n) ? sD[e * np + lane] : 0.0;
-                    h = fma(dv, be, h);
-                }
-                st.h = h;
-                nnls_solve(S, bd, st, 0.0, false, lane);
-                const double rn = sqrt(sse_of(S, st, b[vv], lane));
+                NnlsState<NB> st; st.itmax_hit = 0;
+                project<NB>(S, b[vv], lane, st.h);
+                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+                const double rn = sqrt(sse_of<NB>(S, st, b[vv], lane));
                 if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
                 if (rn < best_r[vv]) {        // np.argmin: first minimum wins
                     best_r[vv] = rn; best_fa[vv] = fa;
-                    best_km[vv] = wave_sum(lane < n ? st.x : 0.0);
+                    double t = 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) t += (lane + 64 * bb < n) ? st.x[bb] : 0.0;
+                    best_km[vv] = wave_sum(t);
                 }
             }
         }
@@ -632,34 +686,21 @@ __global__ __launch_bounds__(256) void finalize_unfitted_kernel(int64_t nvox, in
 }
 
 // motor:443-472 standalone: one wavefront per voxel
+template <int NB>
 __global__ __launch_bounds__(256) void metrics_kernel(int64_t nvox, int n, const double *__restrict__ t2s, double cut_m, double cut_ie,
                                                       const double *__restrict__ fsol, const uint8_t *__restrict__ mask,
                                                       double *__restrict__ maps)
 {
     const int lane = lane_id();
-    const double t2 = (lane < n) ? t2s[lane] : 0.0;
-    const double logt2 = (lane < n) ? log(t2) : 0.0;
-    const bool isM = (lane < n) && (t2 <= cut_m), isIE = (lane < n) && (t2 > cut_m) && (t2 <= cut_ie), isCSF = (lane < n) && (t2 >= cut_ie);
+    MetricLanes<NB> ml;
+    metric_lanes<NB>(ml, t2s, n, cut_m, cut_ie, lane);
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; v < nvox; v += nw) {
-        bool mk = mask ? (mask[v] != 0) : true;
-        double xs = (lane < n && mk) ? fsol[(size_t)v * n + lane] : 0.0;
-        const double epsilon = 1.0e-16;
-        double vt = wave_sum(xs) + epsilon;
-        double xn = xs / vt;
-        double fm = isM ? xn : 0.0, fie = isIE ? xn : 0.0;
-        double lm = isM ? xn * logt2 : 0.0, lie = isIE ? xn * logt2 : 0.0;
-        double fcsf = wave_sum(isCSF ? xn : 0.0);
-        wave_sum2(fm, fie);
-        wave_sum2(lm, lie);
-        if (lane == 0) {
-            maps[0 * nvox + v] = mk ? fm : 0.0;
-            maps[1 * nvox + v] = mk ? fie : 0.0;
-            maps[2 * nvox + v] = mk ? fcsf : 0.0;
-            maps[3 * nvox + v] = mk ? exp(lm / (fm + epsilon)) : 0.0;
-            maps[4 * nvox + v] = mk ? exp(lie / (fie + epsilon)) : 0.0;
-            maps[5 * nvox + v] = mk ? vt : 0.0;
-        }
+        const bool mk = mask ? (mask[v] != 0) : true;
+        double xs[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xs[b] = (lane + 64 * b < n && mk) ? fsol[(size_t)v * n + lane + 64 * b] : 0.0;
+        write_metrics<NB>(ml, xs, mk, maps, nvox, v, lane);
     }
 }
 
@@ -736,16 +777,18 @@ static SortBufs sort_bufs(met2_plan *p)
     return sb;
 }
 
-struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles; };
+struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles, nb; };
 
 static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
 {
     const int n = p->n_t2, m = p->n_te;
+    g.nb = n > 64 ? 2 : 1;
     g.np = n | 1;
     g.kmax = n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
     if (method == MET2_GCV && n * n > g.wave_doubles) g.wave_doubles = n * n;   // k x k support Gram for the Jacobi SVD
-    const size_t shared = sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np);
+    // NB == 1: D and B of one flip angle staged in LDS next to the per-wave factors; NB == 2: they stay in L2
+    const size_t shared = g.nb == 1 ? sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np) : 0;
     const size_t per_wave = sizeof(double) * (size_t)g.wave_doubles;
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
@@ -753,17 +796,23 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
     if (w > 8) w = 8;
     g.waves = w; g.block = 64 * w;
     g.lds = (int)(shared + per_wave * w + 64);
+    // few waves per workgroup (large shapes): several workgroups per CU would not fit in LDS anyway
     g.grid = p->cus > 0 ? p->cus : 256;
     return MET2_OK;
 }
 
+template <int METHOD, int NB>
+static int launch_fit_nb(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
+{
+    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL((fit_kernel<METHOD, NB>), dim3(g.grid), dim3(g.block), g.lds, s, A);
+    HIPCHK(hipGetLastError());
+    return MET2_OK;
+}
 template <int METHOD>
 static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
 {
-    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-    hipLaunchKernelGGL(fit_kernel<METHOD>, dim3(g.grid), dim3(g.block), g.lds, s, A);
-    HIPCHK(hipGetLastError());
-    return MET2_OK;
+    return g.nb == 1 ? launch_fit_nb<METHOD, 1>(A, g, s) : launch_fit_nb<METHOD, 2>(A, g, s);
 }
 
 extern "C" {
@@ -796,7 +845,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
 {
     if (!out) return fail(MET2_E_INVALID, "out is NULL");
     if (n_te < 2 || n_t2 < 2 || n_fa < 1) return fail(MET2_E_INVALID, "bad shape");
-    if (n_t2 > 64) return fail(MET2_E_UNSUPPORTED, "n_t2 > 64 is not built yet (one T2 bin per lane)");
+    if (n_t2 > 128) return fail(MET2_E_UNSUPPORTED, "n_t2 > 128 unsupported (two T2 bins per lane)");
     if (n_te > 63) return fail(MET2_E_UNSUPPORTED, "n_te > 63 unsupported (EPG orders live on the 64 lanes)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MET2_E_NODEVICE, "no HIP device visible");
@@ -811,9 +860,9 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     p->cus = prop.multiProcessorCount;
     HIPCHK(hipMalloc(&p->dD, sizeof(double) * (size_t)n_fa * n_te * n_t2));
     HIPCHK(hipMalloc(&p->dB, sizeof(double) * (size_t)n_fa * n_t2 * n_t2));
-    HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 64));
-    HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 64));
-    HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 64));
+    HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 128));
+    HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 128));
+    HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 8)));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
@@ -939,16 +988,16 @@ int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
         if (K[(size_t)a * n + b] != 0.0) return fail(MET2_E_UNSUPPORTED, "L^T L has bandwidth > 2");
         if (L[(size_t)a * n + b] != 0.0) return fail(MET2_E_UNSUPPORTED, "penalty matrix has bandwidth > 2");
     }
-    std::vector<double> kb(5 * 64, 0.0), lb(5 * 64, 0.0);
+    std::vector<double> kb(5 * 128, 0.0), lb(5 * 128, 0.0);
     for (int j = 0; j < n; ++j) for (int d = 0; d < 5; ++d) {
         int c = j + d - 2;
         if (c < 0 || c >= n) continue;
-        kb[d * 64 + j] = K[(size_t)j * n + c];
-        lb[d * 64 + j] = L[(size_t)j * n + c];
+        kb[d * 128 + j] = K[(size_t)j * n + c];
+        lb[d * 128 + j] = L[(size_t)j * n + c];
     }
     HIPCHK(hipSetDevice(p->opt.device));
-    HIPCHK(hipMemcpy(p->dKband, kb.data(), sizeof(double) * 5 * 64, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->dLband, lb.data(), sizeof(double) * 5 * 64, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dKband, kb.data(), sizeof(double) * 5 * 128, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dLband, lb.data(), sizeof(double) * 5 * 128, hipMemcpyHostToDevice));
     p->Lhost.assign(L, L + (size_t)n * n);
     p->log_detL = log(det_lu(n, L));
     p->have_pen = true;
@@ -1026,10 +1075,10 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     rc = fit_geometry(p, method >= 10 ? method - 10 : method, g);
     if (rc) return rc;
     if (!p->have_pen) {   // plain NNLS never touches the bands, but the kernel loads them
-        HIPCHK(hipMemsetAsync(p->dKband, 0, sizeof(double) * 5 * 64, s));
-        HIPCHK(hipMemsetAsync(p->dLband, 0, sizeof(double) * 5 * 64, s));
+        HIPCHK(hipMemsetAsync(p->dKband, 0, sizeof(double) * 5 * 128, s));
+        HIPCHK(hipMemsetAsync(p->dLband, 0, sizeof(double) * 5 * 128, s));
     }
-    if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 64, s));
+    if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 128, s));
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 8), s));
     const int nb = (int)((nvox + 255) / 256);
@@ -1112,9 +1161,14 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
     A.Dfa = p->dD; A.Bfa = p->dB; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
-    HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
     HIPCHK(hipEventRecord(p->ev0, s));
-    hipLaunchKernelGGL(fa_kernel<4>, dim3(g.grid), dim3(g.block), g.lds, s, A);
+    if (g.nb == 1) {
+        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL((fa_kernel<4, 1>), dim3(g.grid), dim3(g.block), g.lds, s, A);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+        hipLaunchKernelGGL((fa_kernel<2, 2>), dim3(g.grid), dim3(g.block), g.lds, s, A);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev1, s));
     p->timed = true;
@@ -1129,8 +1183,12 @@ int met2_metrics(met2_plan *p, int64_t nvox, const double *fsol, const uint8_t *
     HIPCHK(hipSetDevice(p->opt.device));
     int blocks = (int)((nvox + 3) / 4);
     if (blocks > p->cus * 16) blocks = p->cus * 16;
-    hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nvox, p->n_t2, p->dT2, p->opt.t2_myelin_cut,
-                       p->opt.t2_ie_cut, fsol, mask, maps);
+    if (p->n_t2 <= 64)
+        hipLaunchKernelGGL(metrics_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nvox, p->n_t2, p->dT2, p->opt.t2_myelin_cut,
+                           p->opt.t2_ie_cut, fsol, mask, maps);
+    else
+        hipLaunchKernelGGL(metrics_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nvox, p->n_t2, p->dT2, p->opt.t2_myelin_cut,
+                           p->opt.t2_ie_cut, fsol, mask, maps);
     HIPCHK(hipGetLastError());
     return MET2_OK;
 }

@@ -10,13 +10,15 @@
 //   R^T R = G_PP kept in LDS (append = one forward substitution, removal = Givens
 //   re-triangularisation), ratio test and removal rule as in Lawson-Hanson.
 //
-// Mapping: lane j <-> T2 bin j (n <= 64).  "Position" p is the order in which bins
-// joined the passive set; lane p also holds the position-indexed quantities
-// (ord[p] = bin at position p, y[p] = (R^-T h_P)[p], 1/R[p][p]).
+// Mapping: a lane owns NB T2 bins, bin = lane + 64*b (NB = 1: nT2 <= 64, NB = 2: nT2 <= 128).
+// "Position" p is the order in which bins joined the passive set; lane p&63, slot p>>6 also
+// holds the position-indexed quantities (ord[p] = bin at position p, y[p] = (R^-T h_P)[p],
+// 1/R[p][p]).
 //
-// LDS per workgroup (doubles): sB[n][np]  Gram matrix of the workgroup's flip angle
-//                              sD[m][np]  dictionary rows (np odd -> conflict-free columns)
-//              per wave:       R packed upper-triangular rows, kmax(kmax+1)/2
+// Per wave in LDS: R, packed upper-triangular rows, kmax(kmax+1)/2 doubles.
+// B (n x n) and D (m x n) are read through S.B / S.D: LDS copies of the workgroup's flip angle
+// when they fit (NB = 1; odd row stride -> conflict-free rows and columns), global memory (L2)
+// otherwise.
 #pragma once
 #include "wave_ops.hpp"
 
@@ -30,32 +32,83 @@ __device__ int g_loopstats[8];
 #endif
 
 struct WaveShared {
-    const double *sB;   // [n][np]
-    const double *sD;   // [m][np]
-    double *R;          // this wave's packed factor
-    int n, m, np, kmax;
+    const double *B;    // [n][bstride]
+    const double *D;    // [m][dstride]
+    double *R;          // this wave's LDS region
+    int n, m, bstride, dstride, kmax;
     int rcap;           // doubles available at R
 };
 
-// K = L^T L and L itself as 5 diagonals per lane: kb[d] = K[j][j+d-2], lb[d] = L[j][j+d-2]
+// K = L^T L and L itself as 5 diagonals per owned bin: kb[b][d] = K[j][j+d-2], lb[b][d] = L[j][j+d-2]
+template <int NB>
 struct Band {
-    double kb[5];
-    double lb[5];
+    double kb[NB][5];
+    double lb[NB][5];
 };
 
+template <int NB>
 struct NnlsState {
-    double h;      // (D^T b)_j
-    double x;      // current iterate, bin-indexed
-    double y;      // position-indexed  R^-T h_P
-    double rinv;   // position-indexed  1 / R[p][p]
-    int ord;       // position-indexed  bin at position p
-    int pos;       // bin-indexed       position of bin j, -1 if in Z
-    int k;         // |P|                (uniform)
-    u64 P;         // passive-set mask   (uniform)
-    int itmax_hit; // uniform flag
+    double h[NB];      // (D^T b)_j                     bin-indexed
+    double x[NB];      // current iterate               bin-indexed
+    int pos[NB];       // position of bin j, -1 if in Z bin-indexed
+    double y[NB];      // R^-T h_P                      position-indexed
+    double rinv[NB];   // 1 / R[p][p]                   position-indexed
+    int ord[NB];       // bin at position p             position-indexed
+    int k;             // |P|                (uniform)
+    u64 P[NB];         // passive-set mask   (uniform)
+    int itmax_hit;     // uniform flag
 };
 
 __device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // entry (i,c) at row_base + c
+
+// ---- NB-aware cross-lane helpers (idx / src index bins or positions 0..64*NB-1) ----
+template <int NB>
+__device__ __forceinline__ double bcastN(const double (&v)[NB], int idx)
+{
+    if (NB == 1) return bcast(v[0], idx);
+    double t = (idx >> 6) ? v[NB - 1] : v[0];
+    return bcast(t, idx & 63);
+}
+template <int NB>
+__device__ __forceinline__ int bcastN_i(const int (&v)[NB], int idx)
+{
+    if (NB == 1) return bcast_i(v[0], idx);
+    int t = (idx >> 6) ? v[NB - 1] : v[0];
+    return bcast_i(t, idx & 63);
+}
+template <int NB>
+__device__ __forceinline__ double gatherN(const double (&v)[NB], int src)
+{
+    double lo = gather(v[0], src & 63);
+    if (NB == 1) return lo;
+    double hi = gather(v[NB - 1], src & 63);
+    return ((src >> 6) & 1) ? hi : lo;
+}
+template <int NB>
+__device__ __forceinline__ int gatherN_i(const int (&v)[NB], int src)
+{
+    int lo = gather_i(v[0], src & 63);
+    if (NB == 1) return lo;
+    int hi = gather_i(v[NB - 1], src & 63);
+    return ((src >> 6) & 1) ? hi : lo;
+}
+// index of the first set bit over NB masks (caller guarantees one is set)
+template <int NB>
+__device__ __forceinline__ int first_bit(const u64 (&m)[NB])
+{
+    if (NB == 1) return first_lane(m[0]);
+    return m[0] ? first_lane(m[0]) : 64 + first_lane(m[NB - 1]);
+}
+template <int NB>
+__device__ __forceinline__ void set_bit(u64 (&m)[NB], int idx)
+{
+    if (NB == 2 && (idx >> 6)) m[NB - 1] |= (1ull << (idx & 63)); else m[0] |= (1ull << (idx & 63));
+}
+template <int NB>
+__device__ __forceinline__ void clear_bit(u64 (&m)[NB], int idx)
+{
+    if (NB == 2 && (idx >> 6)) m[NB - 1] &= ~(1ull << (idx & 63)); else m[0] &= ~(1ull << (idx & 63));
+}
 
 __device__ __forceinline__ double band_pick(const double (&b)[5], int d) // d in [-2,2] else 0
 {
@@ -68,16 +121,31 @@ __device__ __forceinline__ double band_pick(const double (&b)[5], int d) // d in
     return v;
 }
 
-// (K v)_j for a bin-indexed vector v (zero outside [0,n))
-__device__ __forceinline__ double band_mul(const double (&b)[5], double v, int lane)
+// value of the bin-indexed vector v at bin (j - d) / (j + d), d in {1,2}; out-of-range bins return
+// arbitrary data (their band coefficient is zero)
+template <int NB>
+__device__ __forceinline__ void shifted(const double (&v)[NB], int d, int lane, double (&below)[NB], double (&above)[NB])
 {
-    double acc = b[2] * v;
-    double t;
-    t = gather(v, (lane + 62) & 63); acc += b[0] * t;   // v[j-2]  (b[0] is zero where j-2 < 0)
-    t = gather(v, (lane + 63) & 63); acc += b[1] * t;   // v[j-1]
-    t = gather(v, (lane + 1) & 63);  acc += b[3] * t;   // v[j+1]  (b[3] zero where j+1 >= n)
-    t = gather(v, (lane + 2) & 63);  acc += b[4] * t;   // v[j+2]
-    return acc;
+    const int lm = (lane - d) & 63, lp = (lane + d) & 63;
+    double lo_m = gather(v[0], lm), lo_p = gather(v[0], lp);
+    if (NB == 1) { below[0] = lo_m; above[0] = lo_p; return; }
+    double hi_m = gather(v[NB - 1], lm), hi_p = gather(v[NB - 1], lp);
+    below[0] = lo_m;                                   // bins < 0 wrap: coefficient zero
+    below[NB - 1] = (lane >= d) ? hi_m : lo_m;         // 64+lane-d: slot 1 if lane >= d else slot 0 lanes 64-d+lane
+    above[0] = (lane + d < 64) ? lo_p : hi_p;
+    above[NB - 1] = hi_p;                              // >= 128 wraps: coefficient zero
+}
+
+// (band matrix) * v for a bin-indexed vector v
+template <int NB>
+__device__ __forceinline__ void band_mul(const double (&bnd)[NB][5], const double (&v)[NB], int lane, double (&out)[NB])
+{
+    double m1[NB], p1[NB], m2[NB], p2[NB];
+    shifted<NB>(v, 1, lane, m1, p1);
+    shifted<NB>(v, 2, lane, m2, p2);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        out[b] = bnd[b][2] * v[b] + bnd[b][0] * m2[b] + bnd[b][1] * m1[b] + bnd[b][3] * p1[b] + bnd[b][4] * p2[b];
 }
 
 // Lawson-Hanson plane rotation (g1)
@@ -92,147 +160,259 @@ __device__ __forceinline__ void givens(double a, double b, double &c, double &s,
     } else { sig = 0.0; c = 0.0; s = 1.0; }
 }
 
-// back substitution R z = y ; returns z position-indexed
-__device__ __forceinline__ double back_subst(const WaveShared &S, const NnlsState &st, int lane)
+// back substitution R z = y ; z position-indexed
+template <int NB>
+__device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<NB> &st, int lane, double (&z)[NB])
 {
     const int k = st.k;
-    const int rbl = row_base(lane, S.kmax);
-    double y = st.y;
-    double rv = (k > 0 && lane < k - 1) ? S.R[rbl + (k - 1)] : 0.0;
-    for (int c = k - 1; c >= 0; --c) {
-        double rvn = (c > 0 && lane < c - 1) ? S.R[rbl + (c - 1)] : 0.0;   // prefetch next column
-        double s = bcast(y * st.rinv, c);
-        y = fma(-rv, s, y);                                                 // lanes >= c are final (rv = 0 there)
-        rv = rvn;
+    double y[NB], rv[NB];
+    int rbl[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        y[b] = st.y[b];
+        rbl[b] = row_base(pl, S.kmax);
+        rv[b] = (k > 0 && pl < k - 1) ? S.R[rbl[b] + (k - 1)] : 0.0;
     }
-    return (lane < k) ? y * st.rinv : 0.0;
+    for (int c = k - 1; c >= 0; --c) {
+        double rvn[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            rvn[b] = (c > 0 && pl < c - 1) ? S.R[rbl[b] + (c - 1)] : 0.0;   // prefetch next column
+        }
+        double t = (NB == 2 && (c >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
+        double s = bcast(t, c & 63);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { y[b] = fma(-rv[b], s, y[b]); rv[b] = rvn[b]; }   // positions >= c are final
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) z[b] = (lane + 64 * b < k) ? y[b] * st.rinv[b] : 0.0;
 }
 
 // Remove position p from the passive set: delete column p of R and re-triangularise.
-__device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState &st, int p, int lane)
+template <int NB>
+__device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &st, int p, int lane)
 {
     const int k = st.k, kmax = S.kmax;
-    const int tb = bcast_i(st.ord, p);
+    const int tb = bcastN_i<NB>(st.ord, p);
     if (p < k - 1) {
-        // rows above p: shift the entries right of column p one place left
-        const bool mv = (lane >= p) && (lane <= k - 2);
+        // rows above p: shift the entries right of column p one place left (all reads, then all writes)
         for (int i = 0; i < p; ++i) {
             const int rb = row_base(i, kmax);
-            double v = mv ? S.R[rb + lane + 1] : 0.0;
-            if (mv) S.R[rb + lane] = v;
+            double v[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int pl = lane + 64 * b;
+                v[b] = (pl >= p && pl <= k - 2) ? S.R[rb + pl + 1] : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int pl = lane + 64 * b;
+                if (pl >= p && pl <= k - 2) S.R[rb + pl] = v[b];
+            }
         }
-        // rows p..k-1: chain of plane rotations, lane = old column index
+        // rows p..k-1: chain of plane rotations, owned index = old column index
         const int rbp = row_base(p, kmax);
-        double carry = (lane > p && lane < k) ? S.R[rbp + lane] : 0.0;
-        double ycar = bcast(st.y, p);
+        double carry[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            carry[b] = (pl > p && pl < k) ? S.R[rbp + pl] : 0.0;
+        }
+        double ycar = bcastN<NB>(st.y, p);
         for (int j = p + 1; j < k; ++j) {
-            const int rbj = row_base(j, kmax);
-            double rowj = (lane >= j && lane < k) ? S.R[rbj + lane] : 0.0;
-            double a = bcast(carry, j), b = bcast(rowj, j);
+            const int rbj = row_base(j, kmax), rbn = row_base(j - 1, kmax);
+            double rowj[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int pl = lane + 64 * b;
+                rowj[b] = (pl >= j && pl < k) ? S.R[rbj + pl] : 0.0;
+            }
+            double a = bcastN<NB>(carry, j), bb = bcastN<NB>(rowj, j);
             double c, s, sig;
-            givens(a, b, c, s, sig);
-            double yj = bcast(st.y, j);
+            givens(a, bb, c, s, sig);
+            double yj = bcastN<NB>(st.y, j);
             double ynew = c * ycar + s * yj;
             ycar = -s * ycar + c * yj;
-            double nv = c * carry + s * rowj;
-            carry = -s * carry + c * rowj;
-            const int rbn = row_base(j - 1, kmax);
-            if (lane > j && lane < k) S.R[rbn + lane - 1] = nv;
-            if (lane == j) S.R[rbn + j - 1] = sig;
-            if (lane == j - 1) { st.y = ynew; st.rinv = 1.0 / sig; }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int pl = lane + 64 * b;
+                double nv = c * carry[b] + s * rowj[b];
+                carry[b] = -s * carry[b] + c * rowj[b];
+                if (pl > j && pl < k) S.R[rbn + pl - 1] = nv;
+                if (pl == j) S.R[rbn + j - 1] = sig;
+                if (pl == j - 1) { st.y[b] = ynew; st.rinv[b] = 1.0 / sig; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    int ordn = gather_i(st.ord, (lane + 1) & 63);
-    st.ord = (lane >= p) ? ordn : st.ord;
-    st.pos = (st.pos > p) ? st.pos - 1 : st.pos;
-    if (lane == tb) { st.pos = -1; st.x = 0.0; }
-    st.P &= ~(1ull << tb);
+    int ordn[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ordn[b] = gatherN_i<NB>(st.ord, lane + 64 * b + 1);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        st.ord[b] = (pl >= p) ? ordn[b] : st.ord[b];
+        st.pos[b] = (st.pos[b] > p) ? st.pos[b] - 1 : st.pos[b];
+        if (pl == tb) { st.pos[b] = -1; st.x[b] = 0.0; }
+    }
+    clear_bit<NB>(st.P, tb);
     st.k = k - 1;
 }
 
-// Try to move bin t from Z to P.  Returns false (state untouched) when the column is
-// numerically dependent on the passive columns or its trial coefficient is not
-// positive (Lawson-Hanson's two acceptance tests).
-__device__ __forceinline__ bool try_append(const WaveShared &S, const Band &bd, NnlsState &st, double lam, int t, int lane,
+// Try to move bin t from Z to P.  Returns false (state untouched) when the column is numerically
+// dependent on the passive columns or -- unless forced -- its trial coefficient is not positive
+// (Lawson-Hanson's two acceptance tests).
+template <int NB>
+__device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int t, int lane,
                                            bool forced = false)
 {
     const int k = st.k, kmax = S.kmax;
-    double gb = (lane < S.n) ? S.sB[t * S.np + lane] : 0.0;
-    gb = fma(lam, band_pick(bd.kb, t - lane), gb);               // G[lane][t]
-    const double gtt = bcast(gb, t);
-    double g = gather(gb, st.ord);                               // position-indexed G[ord_p][t]
-    g = (lane < k) ? g : 0.0;
-    // forward substitution R^T r = g
-    {
-        double rv = (k > 0 && lane > 0 && lane < k) ? S.R[row_base(0, kmax) + lane] : 0.0;
-        for (int i = 0; i < k; ++i) {
-            double rvn = (i + 1 < k && lane > i + 1 && lane < k) ? S.R[row_base(i + 1, kmax) + lane] : 0.0;
-            double s = bcast(g * st.rinv, i);
-            g = fma(-rv, s, g);                                  // lanes <= i are final (rv = 0 there)
-            rv = rvn;
-        }
+    double gb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = lane + 64 * b;
+        gb[b] = (j < S.n) ? S.B[t * S.bstride + j] : 0.0;
+        gb[b] = fma(lam, band_pick(bd.kb[b], t - j), gb[b]);            // G[j][t]
     }
-    const double r = (lane < k) ? g * st.rinv : 0.0;
-    double rr = r * r, ry = r * st.y;       // both zero for lanes >= k
+    const double gtt = bcastN<NB>(gb, t);
+    double g[NB], rv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        double gg = gatherN<NB>(gb, st.ord[b]);                          // position-indexed G[ord_p][t]
+        g[b] = (pl < k) ? gg : 0.0;
+        rv[b] = (k > 0 && pl > 0 && pl < k) ? S.R[row_base(0, kmax) + pl] : 0.0;
+    }
+    // forward substitution R^T r = g
+    for (int i = 0; i < k; ++i) {
+        double rvn[NB];
+        const int rbn = row_base(i + 1, kmax);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            rvn[b] = (i + 1 < k && pl > i + 1 && pl < k) ? S.R[rbn + pl] : 0.0;
+        }
+        double tt = (NB == 2 && (i >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
+        double s = bcast(tt, i & 63);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { g[b] = fma(-rv[b], s, g[b]); rv[b] = rvn[b]; }   // positions <= i are final
+    }
+    double r[NB], rr = 0.0, ry = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        r[b] = (lane + 64 * b < k) ? g[b] * st.rinv[b] : 0.0;
+        rr = fma(r[b], r[b], rr);
+        ry = fma(r[b], st.y[b], ry);
+    }
     wave_sum2(rr, ry);
     const double rho2 = gtt - rr;
     if (!(rho2 > 1e-14 * gtt)) return false;                     // dependent column (noise floor of gtt - r.r)
     const double rho = sqrt(rho2);
-    const double ynew = (bcast(st.h, t) - ry) / rho;
+    const double ynew = (bcastN<NB>(st.h, t) - ry) / rho;
     if (!forced && !(ynew / rho > 0.0)) return false;            // ztest
-    if (lane < k) S.R[row_base(lane, kmax) + k] = r;
-    if (lane == k) { S.R[row_base(k, kmax) + k] = rho; st.rinv = 1.0 / rho; st.y = ynew; st.ord = t; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        if (pl < k) S.R[row_base(pl, kmax) + k] = r[b];
+        if (pl == k) { S.R[row_base(k, kmax) + k] = rho; st.rinv[b] = 1.0 / rho; st.y[b] = ynew; st.ord[b] = t; }
+        if (pl == t) st.pos[b] = k;
+    }
     __builtin_amdgcn_wave_barrier();
-    if (lane == t) st.pos = k;
-    st.P |= (1ull << t);
+    set_bit<NB>(st.P, t);
     st.k = k + 1;
     return true;
 }
 
 // dual vector w = h - (B + lam K) x, bin-indexed
-__device__ __forceinline__ double dual(const WaveShared &S, const Band &bd, const NnlsState &st, double lam, int lane)
+template <int NB>
+__device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double lam, int lane, double (&w)[NB])
 {
-    double acc = 0.0;
+    double acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0;
     const int k = st.k;
     for (int p = 0; p < k; ++p) {
-        int i = bcast_i(st.ord, p);
-        double xi = bcast(st.x, i);
-        double bv = (lane < S.n) ? S.sB[i * S.np + lane] : 0.0;
-        acc = fma(bv, xi, acc);
+        int i = bcastN_i<NB>(st.ord, p);
+        double xi = bcastN<NB>(st.x, i);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = lane + 64 * b;
+            double bv = (j < S.n) ? S.B[i * S.bstride + j] : 0.0;
+            acc[b] = fma(bv, xi, acc[b]);
+        }
     }
-    double w = st.h - acc;
-    if (lam != 0.0) w = fma(-lam, band_mul(bd.kb, st.x, lane), w);
-    return w;
+    double kx[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) kx[b] = 0.0;
+    if (lam != 0.0) band_mul<NB>(bd.kb, st.x, lane, kx);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) w[b] = fma(-lam, kx[b], st.h[b] - acc[b]);
 }
 
 // Lawson-Hanson's secondary loop: from a feasible x and a factor consistent with (P, lambda), move to
 // the solution of the passive sub-problem, dropping variables that hit zero on the way.
 // Returns false when the iteration cap is reached.
-__device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState &st, int &iter, int itmax, int lane)
+template <int NB>
+__device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &st, int &iter, int itmax, int lane)
 {
     for (;;) {
         if (++iter > itmax) return false;
-        double z = back_subst(S, st, lane);                 // position-indexed
-        double xp = gather(st.x, st.ord);                   // x at position
-        bool neg = (lane < st.k) && (z <= 0.0);
-        u64 negm = ballot(neg);
-        double zb = gather(z, st.pos < 0 ? 0 : st.pos);     // bin-indexed
-        zb = (st.pos >= 0) ? zb : 0.0;
-        if (!negm) { st.x = zb; return true; }
-        double ratio = neg ? xp / (xp - z) : 2.0;
-        ratio = (ratio == ratio) ? ratio : 2.0;             // 0/0: Lawson-Hanson's `alpha > t` is false for NaN
-        double alpha = wave_min(ratio);
-        if (!(alpha < 2.0)) { st.x = zb; return true; }     // "alpha still 2": accept z
-        int jj = first_lane(ballot(neg && ratio == alpha));
-        st.x = (st.pos >= 0) ? fma(alpha, zb - st.x, st.x) : 0.0;
-        remove_pos(S, st, jj, lane);
-        for (int sweep = 0; sweep < 64; ++sweep) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
-            double xq = gather(st.x, st.ord);
-            u64 bad = ballot((lane < st.k) && (xq <= 0.0));
-            if (!bad) break;
+        double z[NB], xp[NB], zb[NB], ratio[NB];
+        bool neg[NB];
+        back_subst<NB>(S, st, lane, z);                      // position-indexed
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            xp[b] = gatherN<NB>(st.x, st.ord[b]);            // x at position
+            neg[b] = (pl < st.k) && (z[b] <= 0.0);
+            any = any || (ballot(neg[b]) != 0ull);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double t = gatherN<NB>(z, st.pos[b] < 0 ? 0 : st.pos[b]);   // bin-indexed
+            zb[b] = (st.pos[b] >= 0) ? t : 0.0;
+        }
+        if (!any) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) st.x[b] = zb[b];
+            return true;
+        }
+        double rmin = 2.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double r = neg[b] ? xp[b] / (xp[b] - z[b]) : 2.0;
+            ratio[b] = (r == r) ? r : 2.0;                   // 0/0: Lawson-Hanson's `alpha > t` is false for NaN
+            rmin = fmin(rmin, ratio[b]);
+        }
+        const double alpha = wave_min(rmin);
+        if (!(alpha < 2.0)) {                                // "alpha still 2": accept z
+#pragma unroll
+            for (int b = 0; b < NB; ++b) st.x[b] = zb[b];
+            return true;
+        }
+        u64 hit[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) hit[b] = ballot(neg[b] && ratio[b] == alpha);
+        const int jj = first_bit<NB>(hit);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) st.x[b] = (st.pos[b] >= 0) ? fma(alpha, zb[b] - st.x[b], st.x[b]) : 0.0;
+        remove_pos<NB>(S, st, jj, lane);
+        for (int sweep = 0; sweep < 64 * NB; ++sweep) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
+            u64 bad[NB];
+            bool anyb = false;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                double xq = gatherN<NB>(st.x, st.ord[b]);
+                bad[b] = ballot((lane + 64 * b < st.k) && (xq <= 0.0));
+                anyb = anyb || (bad[b] != 0ull);
+            }
+            if (!anyb) break;
             MET2_STAT(1, sweep + 1);
-            remove_pos(S, st, first_lane(bad), lane);
+            remove_pos<NB>(S, st, first_bit<NB>(bad), lane);
         }
     }
 }
@@ -240,82 +420,136 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState &st, i
 // Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
 // warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
 // (P, lam) -- start with the secondary loop instead of from the empty set.
-__device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band &bd, NnlsState &st, double lam, int mrows, int lane,
+template <int NB>
+__device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
                                              bool warm = false)
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
-    if (warm && st.k > 0 && !nnls_inner(S, st, iter, itmax, lane)) { st.itmax_hit = 1; return; }
+    if (warm && st.k > 0 && !nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit = 1; return; }
     for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows || st.k >= S.kmax) break;
-        double w = dual(S, bd, st, lam, lane);
+        double w[NB];
+        dual<NB>(S, bd, st, lam, lane, w);
         // entering variable: largest positive dual among Z; rejected candidates are skipped
-        u64 rejected = 0;
+        u64 rejected[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) rejected[b] = 0ull;
         bool accepted = false;
-        for (int tries = 0; tries < 64; ++tries) {           // each failed try rejects one more bin
-            bool cand = (lane < n) && !((st.P >> lane) & 1ull) && !((rejected >> lane) & 1ull);
-            double val = cand ? w : -1.0;
-            double wmax = wave_max(val);
+        for (int tries = 0; tries < 64 * NB; ++tries) {      // each failed try rejects one more bin
+            bool cand[NB];
+            double val[NB], vmax = -1.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                cand[b] = (lane + 64 * b < n) && !((st.P[b] >> lane) & 1ull) && !((rejected[b] >> lane) & 1ull);
+                val[b] = cand[b] ? w[b] : -1.0;
+                vmax = fmax(vmax, val[b]);
+            }
+            const double wmax = wave_max(vmax);
             if (!(wmax > 0.0)) break;
-            int t = first_lane(ballot(cand && val == wmax));
-            if (try_append(S, bd, st, lam, t, lane)) { accepted = true; break; }
-            rejected |= (1ull << t);
+            u64 hit[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) hit[b] = ballot(cand[b] && val[b] == wmax);
+            const int t = first_bit<NB>(hit);
+            if (try_append<NB>(S, bd, st, lam, t, lane)) { accepted = true; break; }
+            set_bit<NB>(rejected, t);
             MET2_STAT(0, tries + 1);
         }
         if (!accepted) break;
-        if (!nnls_inner(S, st, iter, itmax, lane)) { st.itmax_hit = 1; break; }
+        if (!nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit = 1; break; }
         MET2_STAT(2, outer + 1);
         MET2_STAT(3, iter);
     }
 }
 
-__device__ __forceinline__ void nnls_reset(NnlsState &st)
+template <int NB>
+__device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 {
-    st.x = 0.0; st.y = 0.0; st.rinv = 0.0; st.ord = 0; st.pos = -1; st.k = 0; st.P = 0ull;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { st.x[b] = 0.0; st.y[b] = 0.0; st.rinv[b] = 0.0; st.ord[b] = 0; st.pos[b] = -1; st.P[b] = 0ull; }
+    st.k = 0;
 }
 
 // cold-start solve; on return st.x is the solution
-__device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band &bd, NnlsState &st, double lam, bool aug, int lane)
+template <int NB>
+__device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
-    nnls_reset(st);
-    nnls_iterate(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
+    nnls_reset<NB>(st);
+    nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
 }
 
 // Warm start: keep the previous solution's passive set and x (a feasible point for any lambda),
 // rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
 // strictly convex problem does not depend on the starting point, so this returns the same x as the
 // cold start up to rounding; it only skips the passes that would rebuild the same passive set.
-__device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band &bd, NnlsState &st, double lam, bool aug, int lane)
+template <int NB>
+__device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
-    const int kold = st.k, ordold = st.ord;
-    if (kold == 0) { nnls_solve(S, bd, st, lam, aug, lane); return; }
-    st.k = 0; st.P = 0ull; st.pos = -1;
+    const int kold = st.k;
+    if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
+    int ordold[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { ordold[b] = st.ord[b]; st.pos[b] = -1; st.P[b] = 0ull; }
+    st.k = 0;
     for (int p = 0; p < kold; ++p) {
-        const int t = bcast_i(ordold, p);
-        if (!try_append(S, bd, st, lam, t, lane, true) && lane == t) st.x = 0.0;   // column became dependent: drop it
+        const int t = bcastN_i<NB>(ordold, p);
+        if (!try_append<NB>(S, bd, st, lam, t, lane, true)) {     // column became dependent: drop it
+#pragma unroll
+            for (int b = 0; b < NB; ++b) if (lane + 64 * b == t) st.x[b] = 0.0;
+        }
     }
-    nnls_iterate(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
+    nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
 }
 
 // D x  (lane e < m holds (D x)_e), using the passive set of st
-__device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsState &st, int lane)
+template <int NB>
+__device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsState<NB> &st, int lane)
 {
     double acc = 0.0;
     for (int p = 0; p < st.k; ++p) {
-        int i = bcast_i(st.ord, p);
-        double xi = bcast(st.x, i);
-        double dv = (lane < S.m) ? S.sD[lane * S.np + i] : 0.0;
+        int i = bcastN_i<NB>(st.ord, p);
+        double xi = bcastN<NB>(st.x, i);
+        double dv = (lane < S.m) ? S.D[lane * S.dstride + i] : 0.0;
         acc = fma(dv, xi, acc);
     }
     return acc;
 }
 
 // || D x - b ||^2
-__device__ __forceinline__ double sse_of(const WaveShared &S, const NnlsState &st, double b, int lane)
+template <int NB>
+__device__ __forceinline__ double sse_of(const WaveShared &S, const NnlsState<NB> &st, double b, int lane)
 {
-    double r = model_signal(S, st, lane) - b;
+    double r = model_signal<NB>(S, st, lane) - b;
     r = (lane < S.m) ? r : 0.0;
     return wave_sum(r * r);
+}
+
+// h = D^T b for the bins a lane owns (bvec: lane e holds echo e)
+template <int NB>
+__device__ __forceinline__ void project(const WaveShared &S, double bvec, int lane, double (&h)[NB])
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b) h[b] = 0.0;
+    for (int e = 0; e < S.m; ++e) {
+        double be = bcast(bvec, e);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = lane + 64 * b;
+            double dv = (j < S.n) ? S.D[e * S.dstride + j] : 0.0;
+            h[b] = fma(dv, be, h[b]);
+        }
+    }
+}
+
+// ||L x||^2 for the bin-indexed x (L as 5 diagonals)
+template <int NB>
+__device__ __forceinline__ double seminorm2(const Band<NB> &bd, const double (&x)[NB], int n, int lane)
+{
+    double lf[NB], s = 0.0;
+    band_mul<NB>(bd.lb, x, lane, lf);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s += (lane + 64 * b < n) ? lf[b] * lf[b] : 0.0;
+    return wave_sum(s);
 }
 
 } // namespace met2
