@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--dims", type=str, default="128,128,64")
     ap.add_argument("--method", type=str, default="X2")
     ap.add_argument("--penalty", type=str, default="L2")
+    ap.add_argument("--nte", type=int, default=32)
+    ap.add_argument("--nt2", type=int, default=60)
+    ap.add_argument("--fa", type=str, default="single", choices=["single", "brute-force"],
+                    help="single: constant FA 150 deg (configs[1]); brute-force: per-voxel FA drawn from the 91-grid and estimated on the device (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--dump-fail", type=str, default="", help="npz path: inputs/outputs of sample voxels whose fsol is >1e-5 off the oracle")
@@ -86,18 +90,25 @@ def main():
 
     nx, ny, nz = (int(v) for v in args.dims.split(","))
     nvox = nx * ny * nz
-    nte, nt2 = 32, 60
+    nte, nt2 = args.nte, args.nt2
     T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
-    alphas = np.array([150.0])                     # "single FA" (configs[1]); index 60 of the 91-grid
+    brute = args.fa == "brute-force"
+    alphas = np.linspace(90.0, 180.0, 91) if brute else np.array([150.0])   # "single FA" = index 60 of the 91-grid
     plan = pkg.Met2Plan(nte, nt2, alphas.shape[0], device=local_rank)
     plan.build_dictionary_epg(T2s, T1s, 10.0, alphas, 3000.0).set_penalty(args.penalty, T2s)
-    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=20260102 + rank, fa_deg=150.0, device=dev)
+    data, fa_true, _ = synth.make_voxels(nvox, nte=nte, seed=20260102 + rank, fa_deg=150.0, fa_values=alphas if brute else None, device=dev)
     out = {k: torch.empty(s, dtype=torch.float64, device=dev) for k, s in
            (("fsol", (nvox, nt2)), ("sig", (nvox, nte)), ("reg", (nvox,)), ("maps", (6, nvox)))}
     out["status"] = torch.empty((nvox,), dtype=torch.int32, device=dev)
 
+    fa_ms = []
+
     def step():
-        res = plan.fit(args.method, data, out=out)
+        fa_idx = None
+        if brute:       # driver step 2 (motor:349-373) on the device, then step 3+4
+            fa_idx, _, _ = plan.fa_bruteforce(data)
+            fa_ms.append(plan.last_kernel_ms())
+        res = plan.fit(args.method, data, fa_index=fa_idx, out=out)
         if world > 1:   # the path's single collective: output maps to the root over xGMI
             _gather(res["maps"])
         return res
@@ -136,14 +147,14 @@ def main():
     if rank == 0:
         fitted = int((out["status"] > 0).sum().item())
         value = world * nvox * args.steps / dt
-        bpv = BYTES_PER_VOXEL[(nte, nt2)]
+        bpv = BYTES_PER_VOXEL.get((nte, nt2), 8 * (2 * nte + nt2) + 65)
         kms = float(np.mean(kernel_ms))
         achieved = fitted * bpv / (kms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("%s_%s_bytes_per_launch" % (args.method, args.penalty))
+                traffic = json.load(open(tfile)).get("%s_%s_bytes_per_launch" % (args.method, args.penalty)) if (nte, nt2, nvox) == (32, 60, 1048576) else None
             except Exception:
                 traffic = None
         line = {
@@ -151,15 +162,19 @@ def main():
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic %dx%dx%d volume, nTE=32, nT2=60, reg_method=%s, reg_matrix=%s, single FA (150 deg)"
-                                   % (nx, ny, nz, args.method, args.penalty),
+            "config": {"workload": "%s: synthetic %dx%dx%d volume, nTE=%d, nT2=%d, reg_method=%s, reg_matrix=%s, %s"
+                                   % ("configs[1]" if (nte, nt2, args.method, args.penalty, brute) == (32, 60, "X2", "L2", False) else "variant",
+                                      nx, ny, nz, nte, nt2, args.method, args.penalty,
+                                      "FA brute-force over 91 flip angles" if brute else "single FA (150 deg)"),
                        "voxels_per_gpu": nvox, "fitted_voxels_per_gpu": fitted, "sharding": "voxel blocks, one per rank"},
             "roofline": {"bound": "hbm", "kernel": "fit_kernel<%s>" % args.method, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kms, "bytes_per_voxel": bpv,
                          "note": "latency/issue-bound fp64 active-set iteration, not HBM-bound (DESIGN.md)"},
         }
-        if not args.no_cpu_baseline:
+        if brute:
+            line["roofline"]["fa_kernel_ms"] = float(np.mean(fa_ms[-args.steps:]))
+        if not args.no_cpu_baseline and not brute:
             cb, (fs_ref, n1) = cpu_baseline(args.method, args.penalty, data[: min(nvox, 1 << 17)].cpu().numpy(), nte, nt2, T2s, T1s,
                                             alphas, synth.lambda_grid(), seconds=args.cpu_seconds)
             line["cpu_baseline"] = cb

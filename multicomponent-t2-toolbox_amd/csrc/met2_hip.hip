@@ -786,7 +786,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
     g.np = n | 1;
     g.kmax = n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
-    if (method == MET2_GCV && n * n > g.wave_doubles) g.wave_doubles = n * n;   // k x k support Gram for the Jacobi SVD
+    if (method == MET2_GCV && (m + 1) * n > g.wave_doubles) g.wave_doubles = (m + 1) * n;   // E^T (k x (m+1)) for the Jacobi SVD
     // NB == 1: D and B of one flip angle staged in LDS next to the per-wave factors; NB == 2: they stay in L2
     const size_t shared = g.nb == 1 ? sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np) : 0;
     const size_t per_wave = sizeof(double) * (size_t)g.wave_doubles;
@@ -1129,7 +1129,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
 #ifdef MET2_LOOPSTATS
         int ls[8];
         HIPCHK(hipMemcpyFromSymbol(ls, HIP_SYMBOL(met2::g_loopstats), sizeof(ls)));
-        fprintf(stderr, "[met2] loop maxima: tries=%d sweeps=%d outer=%d iter=%d taken=%d round=%d\n", ls[0], ls[1], ls[2], ls[3], ls[4], ls[5]);
+        fprintf(stderr, "[met2] loop maxima: tries=%d sweeps=%d outer=%d iter=%d taken=%d round=%d jacobi_sweeps=%d last_sweep_rotations=%d\n", ls[0], ls[1], ls[2], ls[3], ls[4], ls[5], ls[6], ls[7]);
 #endif
         fflush(stderr);
     }

@@ -115,17 +115,21 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
     return cost1 + cost2;
 }
 
-// algorithms.py:285-296 given the NNLS solution st.x at lambda = x.
-// trace(Dr G^+ Dr^T) with G = Dr^T Dr + x*(sum_S L_jj^2) * ones, G^+ = SVD-truncated pseudo-inverse
-// (singular values <= eps*k*s_max dropped, np.linalg.lstsq(rcond=None)).  One-sided Jacobi on the
-// columns of G held column-major in S.R (k*k <= rcap), a lane owns rows lane + 64 b; u = 1^T V is carried
-// along so that trace = sum_retained (1 - c u_i^2 / lambda_i)  (G symmetric: G v_i = lambda_i v_i,
-// Dr^T Dr = G - c 11^T).
+// algorithms.py:285-296 given the NNLS solution st.x at lambda = x:
+//   log( (r^2/m) / ((m - trace(Dr G^+ Dr^T))/m)^2 ),  G = Dr^T Dr + c 11^T,  c = x * sum_{j in S} L_jj^2
+// (the scalar-broadcast quirk of algorithms.py:289-293), G^+ = SVD-truncated pseudo-inverse with
+// np.linalg.lstsq's cutoff eps*k*s_max.  With E = [Dr; sqrt(c) 1^T] ((m+1) x k) one has G = E^T E, so
+// the singular values of G are the squared singular values of E and, for E = U S V^T,
+//   trace(Dr G^+ Dr^T) = sum_{kept i} (1 - U[m][i]^2).
+// E^T (k x (m+1)) is small in its column count whatever the support size: one-sided Jacobi on its
+// m+1 columns (lane = support row, NB slots), carrying only the last row of the accumulated
+// rotations.  Column norms are cached per lane and refreshed every sweep; pairs whose columns both sit
+// far below the cutoff are skipped.
 template <int NB>
 __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double x, double b,
                                                 int lane, int &overflow)
 {
-    const int n = S.n, m = S.m;
+    const int n = S.n, m = S.m, mm = m + 1;
     const double sse = sse_of<NB>(S, st, b, lane);
     const double rn2 = sse + x * seminorm2<NB>(bd, st.x, n, lane);   // squared residual norm of the augmented system
     bool inS[NB];
@@ -141,7 +145,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         l2 += inS[bb] ? ld * ld : 0.0;
     }
     if (k == 0) return NAN;
-    if (k * k > S.rcap) { overflow = 1; return INFINITY; }
+    if (mm * k > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
     // support list through LDS: rank-th support bin -> sp of the owner of row `rank`
     int *list = (int *)S.R;
@@ -157,74 +161,66 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) sp[bb] = (lane + 64 * bb < k) ? list[lane + 64 * bb] : 0;
     __builtin_amdgcn_wave_barrier();
-    double *A = S.R;                                                       // column-major k x k
-    for (int q = 0; q < k; ++q) {
-        const int sq = bcastN_i<NB>(sp, q);
+    double *A = S.R;                                   // column-major k x (m+1): A[e*k + r] = E[e][s_r]
+    const double sc = sqrt(c);
+    for (int e = 0; e < mm; ++e) {
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
             const int r = lane + 64 * bb;
-            if (r < k) A[q * k + r] = S.B[sq * S.bstride + sp[bb]] + c;
+            if (r < k) A[e * k + r] = (e < m) ? S.D[e * S.dstride + sp[bb]] : sc;
         }
     }
     __builtin_amdgcn_wave_barrier();
-    double u[NB];
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) u[bb] = (lane + 64 * bb < k) ? 1.0 : 0.0;      // owner of q holds u_q = 1^T v_q
-    for (int sweep = 0; sweep < 40; ++sweep) {
+    double wl = (lane == m) ? 1.0 : 0.0;               // lane e: last row of the accumulated rotations
+    double cn2 = 0.0;                                  // lane e: ||column e||^2
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        // refresh the cached column norms (lane e walks its own column)
+        cn2 = 0.0;
+        for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; cn2 = fma(v, v, cn2); }
+        const double big = wave_max(lane < mm ? cn2 : 0.0);
+        const double floor2 = 1e-6 * (2.220446049250313e-16 * (double)k * big);   // far below lstsq's cutoff on sigma^2
+        const double noise = 4.0 * 2.220446049250313e-16 * sqrt(big * (double)k);
         int rotated = 0;
-        for (int p = 0; p < k - 1; ++p)
-            for (int q = p + 1; q < k; ++q) {
-                double ap[NB], aq[NB], alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (int p = 0; p < mm - 1; ++p)
+            for (int q = p + 1; q < mm; ++q) {
+                const double alpha = bcast(cn2, p), beta = bcast(cn2, q);
+                if (alpha < floor2 && beta < floor2) continue;
+                double ap[NB], aq[NB], gamma = 0.0;
 #pragma unroll
                 for (int bb = 0; bb < NB; ++bb) {
                     const int r = lane + 64 * bb;
                     ap[bb] = (r < k) ? A[p * k + r] : 0.0;
                     aq[bb] = (r < k) ? A[q * k + r] : 0.0;
-                    alpha = fma(ap[bb], ap[bb], alpha); beta = fma(aq[bb], aq[bb], beta); gamma = fma(ap[bb], aq[bb], gamma);
+                    gamma = fma(ap[bb], aq[bb], gamma);
                 }
-                wave_sum2(alpha, beta);
                 gamma = wave_sum(gamma);
-                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
-                rotated = 1;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                const double up = bcastN<NB>(u, p), uq = bcastN<NB>(u, q);
+                // converged pair: orthogonal to working precision, or the inner product is at the level of the
+                // absolute rounding noise (eps * sqrt(big) per entry) that cancellation left in small columns
+                if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta) || fabs(gamma) <= noise * sqrt(fmax(alpha, beta))) continue;
+                rotated += 1;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                const double wp = bcast(wl, p), wq = bcast(wl, q);
 #pragma unroll
                 for (int bb = 0; bb < NB; ++bb) {
                     const int r = lane + 64 * bb;
                     if (r < k) { A[p * k + r] = cs * ap[bb] - sn * aq[bb]; A[q * k + r] = sn * ap[bb] + cs * aq[bb]; }
-                    if (r == p) u[bb] = cs * up - sn * uq;
-                    if (r == q) u[bb] = sn * up + cs * uq;
                 }
+                if (lane == p) { wl = cs * wp - sn * wq; cn2 = alpha - t * gamma; }
+                if (lane == q) { wl = sn * wp + cs * wq; cn2 = beta + t * gamma; }
             }
+        MET2_STAT(6, sweep + 1);
+        MET2_STAT(7, rotated);
         if (!rotated) break;
     }
     __builtin_amdgcn_wave_barrier();
-    // singular values = column norms: the owner of q runs down column q
-    double sv[NB], colsum[NB], svmax = 0.0;
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-        const int q = lane + 64 * bb;
-        double s2 = 0.0, cs = 0.0;
-        for (int r = 0; r < k; ++r) {
-            double v = (q < k) ? A[q * k + r] : 0.0;
-            s2 = fma(v, v, s2); cs += v;
-        }
-        sv[bb] = sqrt(s2); colsum[bb] = cs;
-        svmax = fmax(svmax, q < k ? sv[bb] : 0.0);
-    }
-    const double smax = wave_max(svmax);
+    cn2 = 0.0;
+    for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; cn2 = fma(v, v, cn2); }
+    const double smax = wave_max(lane < mm ? cn2 : 0.0);                 // singular values of G = sigma(E)^2
     const double cut = 2.220446049250313e-16 * (double)k * smax;
-    double trp = 0.0;
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-        const bool keep = (lane + 64 * bb < k) && (sv[bb] > cut);
-        // sign of the eigenvalue: 1^T A_q = lambda_q u_q
-        const double lamq = (colsum[bb] * u[bb] >= 0.0) ? sv[bb] : -sv[bb];
-        trp += keep ? (1.0 - c * u[bb] * u[bb] / lamq) : 0.0;
-    }
-    const double tr = wave_sum(trp);
+    const bool keep = (lane < mm) && (cn2 > cut);
+    const double tr = wave_sum(keep ? (1.0 - wl * wl) : 0.0);
     const double num = (1.0 / m) * rn2;
     const double den = (1.0 / m) * ((double)m - tr);
     return log(num / (den * den));
