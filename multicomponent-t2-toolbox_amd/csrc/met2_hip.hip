@@ -384,14 +384,13 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 
 // METHOD: met2_method, or 10 + method for the objective-grid diagnostic.  NB: T2 bins per lane.
 // NB == 1: D and B of the workgroup's flip angle are staged in LDS; NB == 2: read from L2.
-template <int METHOD, int NB>
-__global__ __launch_bounds__(512) void fit_kernel(FitArgs A)
+template <int METHOD, int NB, bool STAGE>
+__global__ __launch_bounds__(768) void fit_kernel(FitArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, np = A.np, kmax = A.kmax;
     const int tri = A.wave_doubles;
-    constexpr bool STAGE = (NB == 1);
     double *sB = smem;
     double *sD = sB + (STAGE ? n * np : 0);
     double *sR0 = sD + (STAGE ? m * np : 0);
@@ -777,9 +776,9 @@ static SortBufs sort_bufs(met2_plan *p)
     return sb;
 }
 
-struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles, nb; };
+struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles, nb, stage; };
 
-static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
+static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allow_unstaged = true)
 {
     const int n = p->n_t2, m = p->n_te;
     g.nb = n > 64 ? 2 : 1;
@@ -787,13 +786,20 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
     g.kmax = n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
     if (method == MET2_GCV && (m + 1) * n > g.wave_doubles) g.wave_doubles = (m + 1) * n;   // E^T (k x (m+1)) for the Jacobi SVD
-    // NB == 1: D and B of one flip angle staged in LDS next to the per-wave factors; NB == 2: they stay in L2
-    const size_t shared = g.nb == 1 ? sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np) : 0;
+    // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
+    // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
+    // only ~k rows of B, so the fit kernel prefers the LDS for three more resident waves per CU (measured:
+    // staged 8 waves 1.555 M voxels/s, unstaged 8 waves 1.485 M, unstaged 11 waves 1.821 M on X2/L2);
+    // the brute-force FA kernel (cold solves, B-row heavy) stages.
+    g.stage = (g.nb == 1 && !allow_unstaged) ? 1 : 0;
+    if (const char *e = getenv("MET2_STAGE")) if (allow_unstaged) g.stage = (g.nb == 1 && atoi(e) != 0) ? 1 : 0;
+    const size_t shared = g.stage ? sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np) : 0;
     const size_t per_wave = sizeof(double) * (size_t)g.wave_doubles;
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
     int w = (int)((budget - shared) / per_wave);
-    if (w > 8) w = 8;
+    if (w > 12) w = 12;
+    if (const char *e = getenv("MET2_WAVES")) { int ww = atoi(e); if (ww >= 1 && ww < w) w = ww; }
     g.waves = w; g.block = 64 * w;
     g.lds = (int)(shared + per_wave * w + 64);
     // few waves per workgroup (large shapes): several workgroups per CU would not fit in LDS anyway
@@ -801,18 +807,19 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g)
     return MET2_OK;
 }
 
-template <int METHOD, int NB>
+template <int METHOD, int NB, bool STAGE>
 static int launch_fit_nb(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
 {
-    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-    hipLaunchKernelGGL((fit_kernel<METHOD, NB>), dim3(g.grid), dim3(g.block), g.lds, s, A);
+    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL((fit_kernel<METHOD, NB, STAGE>), dim3(g.grid), dim3(g.block), g.lds, s, A);
     HIPCHK(hipGetLastError());
     return MET2_OK;
 }
 template <int METHOD>
 static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
 {
-    return g.nb == 1 ? launch_fit_nb<METHOD, 1>(A, g, s) : launch_fit_nb<METHOD, 2>(A, g, s);
+    if (g.nb == 2) return launch_fit_nb<METHOD, 2, false>(A, g, s);
+    return g.stage ? launch_fit_nb<METHOD, 1, true>(A, g, s) : launch_fit_nb<METHOD, 1, false>(A, g, s);
 }
 
 extern "C" {
@@ -1153,8 +1160,9 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     HIPCHK(hipSetDevice(p->opt.device));
     hipStream_t s = (hipStream_t)stream;
     LaunchGeom g;
-    int rc = fit_geometry(p, MET2_NNLS, g);
+    int rc = fit_geometry(p, MET2_NNLS, g, false);
     if (rc) return rc;
+    if (g.waves > 8) { g.waves = 8; g.block = 512; }
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
