@@ -132,10 +132,12 @@ def main():
         step()
     sync()
     kernel_ms = []
+    pass2_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         kernel_ms.append(plan.last_kernel_ms())
+        pass2_ms.append(plan.last_second_pass_ms())
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -169,7 +171,7 @@ def main():
                        "voxels_per_gpu": nvox, "fitted_voxels_per_gpu": fitted, "sharding": "voxel blocks, one per rank"},
             "roofline": {"bound": "hbm", "kernel": "fit_kernel<%s>" % args.method, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kms, "bytes_per_voxel": bpv,
+                         "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "bytes_per_voxel": bpv,
                          "note": "latency/issue-bound fp64 active-set iteration, not HBM-bound (DESIGN.md)"},
         }
         if brute:

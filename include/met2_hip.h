@@ -156,6 +156,11 @@ int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_
 /* Duration in ms of the solver kernel of the most recent met2_fit / met2_fa_bruteforce on
  * this plan, measured with HIP events on the launch stream (blocks until it finished). */
 int met2_plan_last_kernel_ms(met2_plan *plan, double *ms);
+/* NNLS/T2SPARC/X2/L-curve fits run in two passes: the solver kernel with a passive-set capacity of 0.8 n_t2
+ * (more resident waves per CU), then the same kernel at full capacity for the voxels that hit the cap.
+ * met2_plan_last_kernel_ms times the first (dominant) launch; this gives the second pass (requeue + launch),
+ * 0 when there was none. */
+int met2_plan_last_second_pass_ms(met2_plan *plan, double *ms);
 
 /* Launch geometry of the solver kernel (for reports): workgroups, threads per workgroup,
  * dynamic LDS bytes per workgroup. */

@@ -186,6 +186,27 @@ __global__ __launch_bounds__(256) void scatter_kernel(int64_t nvox, SortBufs sb)
     }
 }
 
+// second pass of the capacity scheme: voxels whose passive set hit the fast path's kmax are queued again
+__global__ __launch_bounds__(256) void requeue_overflow_kernel(int64_t nvox, const double *__restrict__ fa_index,
+                                                               const int32_t *__restrict__ status, SortBufs sb)
+{
+    const int lane = lane_id();
+    int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int key = -1;
+    if (v < nvox) {
+        if (status[v] & MET2_ST_KOVERFLOW) key = fa_index ? (int)fa_index[v] : 0;
+        sb.key[v] = key;
+    }
+    u64 todo = ballot(key >= 0);
+    while (todo) {
+        int leader = first_lane(todo);
+        int k0 = bcast_i(key, leader);
+        u64 same = ballot(key == k0) & todo;
+        if (lane == leader) atomicAdd(&sb.hist[k0], __popcll(same));
+        todo &= ~same;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fit kernel
 // ------------------------------------------------------------------------------------------
@@ -384,8 +405,14 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 
 // METHOD: met2_method, or 10 + method for the objective-grid diagnostic.  NB: T2 bins per lane.
 // NB == 1: D and B of the workgroup's flip angle are staged in LDS; NB == 2: read from L2.
-template <int METHOD, int NB, bool STAGE>
-__global__ __launch_bounds__(768) void fit_kernel(FitArgs A)
+// Waves per workgroup the kernel is compiled for: 16 (128 VGPRs) where the method fits that budget without
+// spilling (NNLS, T2SPARC, X2, L-curve), 12 (168 VGPRs) for the two with a second large phase (GCV, BayesReg).
+__host__ __device__ constexpr int method_max_waves(int method) { return (method <= MET2_LCURVE) ? 16 : 12; }
+
+// SECOND only gives the second pass of the capacity scheme its own kernel symbol (profilers then list the
+// dominant first pass and the small clean-up pass separately); the code is identical.
+template <int METHOD, int NB, bool STAGE, bool SECOND>
+__global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -538,7 +565,8 @@ __global__ __launch_bounds__(768) void fit_kernel(FitArgs A)
                 if (lane == 0) { A.reg[v] = 0.0; if (A.status) A.status[v] = stat | (overflow ? MET2_ST_KOVERFLOW : 0); }
                 continue;
             }
-            if (st.itmax_hit) stat |= MET2_ST_ITMAX;
+            if (st.itmax_hit & 1) stat |= MET2_ST_ITMAX;
+            if (st.itmax_hit & 2) stat |= MET2_ST_KOVERFLOW;
 
             // ---- epilogue: un-normalise (motor:153-155) + metrics (motor:448-468)
             double xs[NB];
@@ -722,9 +750,10 @@ struct met2_plan {
     double log_detL = 0.0;      // log(det(L)) as bayesian_interpolation.py:100,123 uses it (-inf for L2)
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
-    int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;
+    int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    bool timed = false, timed2 = false;
 };
 
 // determinant by LU with partial pivoting (scipy.linalg.det at bayesian_interpolation.py:100)
@@ -778,18 +807,19 @@ static SortBufs sort_bufs(met2_plan *p)
 
 struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles, nb, stage; };
 
-static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allow_unstaged = true)
+// kmax_cap > 0: capacity of the passive set for this launch (fast path); 0: full capacity n.
+static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allow_unstaged = true, int kmax_cap = 0)
 {
     const int n = p->n_t2, m = p->n_te;
     g.nb = n > 64 ? 2 : 1;
     g.np = n | 1;
-    g.kmax = n;
+    g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
     if (method == MET2_GCV && (m + 1) * n > g.wave_doubles) g.wave_doubles = (m + 1) * n;   // E^T (k x (m+1)) for the Jacobi SVD
     // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
     // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
-    // only ~k rows of B, so the fit kernel prefers the LDS for three more resident waves per CU (measured:
-    // staged 8 waves 1.555 M voxels/s, unstaged 8 waves 1.485 M, unstaged 11 waves 1.821 M on X2/L2);
+    // only ~k rows of B, so the fit kernel prefers the LDS for more resident waves per CU (measured on X2/L2:
+    // staged 8 waves 1.555 M voxels/s, unstaged 8 waves 1.485 M, unstaged 11 waves 1.821 M);
     // the brute-force FA kernel (cold solves, B-row heavy) stages.
     g.stage = (g.nb == 1 && !allow_unstaged) ? 1 : 0;
     if (const char *e = getenv("MET2_STAGE")) if (allow_unstaged) g.stage = (g.nb == 1 && atoi(e) != 0) ? 1 : 0;
@@ -798,29 +828,63 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
     int w = (int)((budget - shared) / per_wave);
-    if (w > 12) w = 12;
+    const int wmax = method_max_waves(method);
+    if (w > wmax) w = wmax;
     if (const char *e = getenv("MET2_WAVES")) { int ww = atoi(e); if (ww >= 1 && ww < w) w = ww; }
     g.waves = w; g.block = 64 * w;
     g.lds = (int)(shared + per_wave * w + 64);
-    // few waves per workgroup (large shapes): several workgroups per CU would not fit in LDS anyway
     g.grid = p->cus > 0 ? p->cus : 256;
     return MET2_OK;
 }
 
-template <int METHOD, int NB, bool STAGE>
+// Fast-path capacity: the passive set rarely exceeds ~0.75 n (X2/L2 at nT2=60 peaks at 42-45 on the first,
+// large-lambda Brent points), and LDS per wave grows with kmax^2.  Methods whose second phase needs the
+// full n x n region (BayesReg) or their own matrix (GCV) do not use it.
+static int fast_kmax(const met2_plan *p, int method)
+{
+    if (method == MET2_BAYESREG || method == MET2_GCV || method >= 10) return 0;
+    if (const char *e = getenv("MET2_KMAX")) { int kk = atoi(e); return (kk >= 8 && kk < p->n_t2) ? kk : 0; }
+    const int k = (4 * p->n_t2 + 4) / 5;      // ceil(0.8 n)
+    return k < p->n_t2 ? k : 0;
+}
+
+template <int METHOD, int NB, bool STAGE, bool SECOND>
 static int launch_fit_nb(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
 {
-    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-    hipLaunchKernelGGL((fit_kernel<METHOD, NB, STAGE>), dim3(g.grid), dim3(g.block), g.lds, s, A);
+    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB, STAGE, SECOND>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL((fit_kernel<METHOD, NB, STAGE, SECOND>), dim3(g.grid), dim3(g.block), g.lds, s, A);
     HIPCHK(hipGetLastError());
     return MET2_OK;
 }
 template <int METHOD>
-static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
+static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s, bool second = false)
 {
-    if (g.nb == 2) return launch_fit_nb<METHOD, 2, false>(A, g, s);
-    return g.stage ? launch_fit_nb<METHOD, 1, true>(A, g, s) : launch_fit_nb<METHOD, 1, false>(A, g, s);
+    if (second) {      // only the capacity-scheme methods have a second pass
+        if (METHOD > MET2_LCURVE) return fail(MET2_E_INVALID, "no second pass for this method");
+        constexpr int M2 = METHOD > MET2_LCURVE ? MET2_NNLS : METHOD;
+        if (g.nb == 2) return launch_fit_nb<M2, 2, false, true>(A, g, s);
+        return g.stage ? launch_fit_nb<M2, 1, true, true>(A, g, s) : launch_fit_nb<M2, 1, false, true>(A, g, s);
+    }
+    if (g.nb == 2) return launch_fit_nb<METHOD, 2, false, false>(A, g, s);
+    return g.stage ? launch_fit_nb<METHOD, 1, true, false>(A, g, s) : launch_fit_nb<METHOD, 1, false, false>(A, g, s);
 }
+
+static int launch_method(int method, const FitArgs &A, const LaunchGeom &g, hipStream_t s, bool second = false)
+{
+    switch (method) {
+    case 10 + MET2_X2: return launch_fit<10 + MET2_X2>(A, g, s);
+    case 10 + MET2_GCV: return launch_fit<10 + MET2_GCV>(A, g, s);
+    case 10 + MET2_BAYESREG: return launch_fit<10 + MET2_BAYESREG>(A, g, s);
+    case MET2_NNLS: return launch_fit<MET2_NNLS>(A, g, s, second);
+    case MET2_T2SPARC: return launch_fit<MET2_T2SPARC>(A, g, s, second);
+    case MET2_X2: return launch_fit<MET2_X2>(A, g, s, second);
+    case MET2_LCURVE: return launch_fit<MET2_LCURVE>(A, g, s, second);
+    case MET2_GCV: return launch_fit<MET2_GCV>(A, g, s);
+    case MET2_BAYESREG: return launch_fit<MET2_BAYESREG>(A, g, s);
+    default: return fail(MET2_E_UNSUPPORTED, "method not built");
+    }
+}
+
 
 extern "C" {
 
@@ -873,6 +937,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 8)));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
+    HIPCHK(hipEventCreate(&p->ev2));
     std::vector<double> g;
     default_lambda_grid(g);
     *out = p;
@@ -898,10 +963,11 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     (void)hipSetDevice(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dKband, p->dLband, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall};
+    void *bufs[] = {p->dD, p->dB, p->dKband, p->dLband, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
     for (void *b : bufs) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->ev2) (void)hipEventDestroy(p->ev2);
     delete p;
     return MET2_OK;
 }
@@ -1078,9 +1144,21 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_sort_bufs(p, nvox);
     if (rc) return rc;
-    LaunchGeom g;
-    rc = fit_geometry(p, method >= 10 ? method - 10 : method, g);
+    // capacity scheme: pass 1 with a passive-set capacity kfast < n (more waves per CU), pass 2 with the full
+    // capacity for the voxels that hit it
+    const int kfast = objgrid ? 0 : fast_kmax(p, method);
+    LaunchGeom g, g2;
+    rc = fit_geometry(p, method, g, true, kfast);
     if (rc) return rc;
+    if (kfast) { rc = fit_geometry(p, method, g2, true, 0); if (rc) return rc; }
+    if (kfast && !status) {        // the second pass is driven by the status words
+        if (p->cap_status < nvox) {
+            if (p->dStatus) HIPCHK(hipFree(p->dStatus));
+            HIPCHK(hipMalloc(&p->dStatus, sizeof(int32_t) * (size_t)nvox));
+            p->cap_status = nvox;
+        }
+        status = p->dStatus;
+    }
     if (!p->have_pen) {   // plain NNLS never touches the bands, but the kernel loads them
         HIPCHK(hipMemsetAsync(p->dKband, 0, sizeof(double) * 5 * 128, s));
         HIPCHK(hipMemsetAsync(p->dLband, 0, sizeof(double) * 5 * 128, s));
@@ -1116,20 +1194,25 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
 
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }
-    switch (objgrid ? method + 10 : method) {
-    case 10 + MET2_X2: rc = launch_fit<10 + MET2_X2>(A, g, s); break;
-    case 10 + MET2_GCV: rc = launch_fit<10 + MET2_GCV>(A, g, s); break;
-    case 10 + MET2_BAYESREG: rc = launch_fit<10 + MET2_BAYESREG>(A, g, s); break;
-    case MET2_NNLS: rc = launch_fit<MET2_NNLS>(A, g, s); break;
-    case MET2_T2SPARC: rc = launch_fit<MET2_T2SPARC>(A, g, s); break;
-    case MET2_X2: rc = launch_fit<MET2_X2>(A, g, s); break;
-    case MET2_LCURVE: rc = launch_fit<MET2_LCURVE>(A, g, s); break;
-    case MET2_GCV: rc = launch_fit<MET2_GCV>(A, g, s); break;
-    case MET2_BAYESREG: rc = launch_fit<MET2_BAYESREG>(A, g, s); break;
-    default: rc = fail(MET2_E_UNSUPPORTED, "method not built");
-    }
+    rc = launch_method(objgrid ? method + 10 : method, A, g, s);
     if (rc) return rc;
     HIPCHK(hipEventRecord(p->ev1, s));
+    if (kfast) {
+        // gated-out voxels are finalised from the first pass's keys, then the key/perm buffers are reused
+        hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
+                           sig, reg, lam, maps);
+        HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 1), s));     // all but the error word
+        hipLaunchKernelGGL(requeue_overflow_kernel, dim3(nb), dim3(256), 0, s, nvox, fa_index, status, sb);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
+        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
+        HIPCHK(hipGetLastError());
+        FitArgs A2 = A;
+        A2.kmax = g2.kmax; A2.waves = g2.waves; A2.wave_doubles = g2.wave_doubles;
+        rc = launch_method(method, A2, g2, s, true);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(p->ev2, s));
+        p->timed2 = true;
+    } else p->timed2 = false;
     p->timed = true;
     if (dbg) {
         HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit kernel done\n");
@@ -1140,9 +1223,11 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
 #endif
         fflush(stderr);
     }
-    hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
-                       objgrid ? nullptr : sig, reg, objgrid ? nullptr : lam, objgrid ? nullptr : maps);
-    HIPCHK(hipGetLastError());
+    if (!kfast) {
+        hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
+                           objgrid ? nullptr : sig, reg, objgrid ? nullptr : lam, objgrid ? nullptr : maps);
+        HIPCHK(hipGetLastError());
+    }
     // FA index range errors are reported synchronously (they would be IndexError in the reference)
     int herr = 0;
     HIPCHK(hipMemcpyAsync(&herr, sb.err, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1162,7 +1247,7 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     LaunchGeom g;
     int rc = fit_geometry(p, MET2_NNLS, g, false);
     if (rc) return rc;
-    if (g.waves > 8) { g.waves = 8; g.block = 512; }
+    if (g.waves > 8) { g.waves = 8; g.block = 512; g.lds = (int)(sizeof(double) * ((size_t)p->n_t2 * g.np + (size_t)p->n_te * g.np) * (g.stage ? 1 : 0) + sizeof(double) * (size_t)g.wave_doubles * 8 + 64); }
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
@@ -1213,11 +1298,25 @@ int met2_plan_last_kernel_ms(met2_plan *p, double *ms)
     return MET2_OK;
 }
 
+int met2_plan_last_second_pass_ms(met2_plan *p, double *ms)
+{
+    if (!p || !ms) return fail(MET2_E_INVALID, "NULL argument");
+    *ms = 0.0;
+    if (!p->timed || !p->timed2) return MET2_OK;
+    HIPCHK(hipSetDevice(p->opt.device));
+    HIPCHK(hipEventSynchronize(p->ev2));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, p->ev1, p->ev2));
+    *ms = (double)f;
+    return MET2_OK;
+}
+
 int met2_plan_launch_info(met2_plan *p, int32_t method, int32_t *grid, int32_t *block, int32_t *lds_bytes)
 {
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
     LaunchGeom g;
-    int rc = fit_geometry(p, method, g);
+    const int kf = fast_kmax(p, method);
+    int rc = fit_geometry(p, method, g, true, kf);
     if (rc) return rc;
     if (grid) *grid = g.grid;
     if (block) *block = g.block;

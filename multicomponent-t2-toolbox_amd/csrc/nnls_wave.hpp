@@ -56,7 +56,7 @@ struct NnlsState {
     int ord[NB];       // bin at position p             position-indexed
     int k;             // |P|                (uniform)
     u64 P[NB];         // passive-set mask   (uniform)
-    int itmax_hit;     // uniform flag
+    int itmax_hit;     // uniform flags: bit0 iteration cap reached, bit1 passive set hit the capacity kmax < n
 };
 
 __device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // entry (i,c) at row_base + c
@@ -426,9 +426,10 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
-    if (warm && st.k > 0 && !nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit = 1; return; }
+    if (warm && st.k > 0 && !nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
     for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
-        if (st.k >= n || st.k >= mrows || st.k >= S.kmax) break;
+        if (st.k >= n || st.k >= mrows) break;
+        if (st.k >= S.kmax) { st.itmax_hit |= 2; break; }   // capacity of the fast path: the voxel is redone with kmax = n
         double w[NB];
         dual<NB>(S, bd, st, lam, lane, w);
         // entering variable: largest positive dual among Z; rejected candidates are skipped
@@ -456,7 +457,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
             MET2_STAT(0, tries + 1);
         }
         if (!accepted) break;
-        if (!nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit = 1; break; }
+        if (!nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; break; }
         MET2_STAT(2, outer + 1);
         MET2_STAT(3, iter);
     }

@@ -178,6 +178,11 @@ class Met2Plan:
         check(lib().met2_plan_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_second_pass_ms(self):
+        ms = C.c_double(0.0)
+        check(lib().met2_plan_last_second_pass_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def launch_info(self, method="X2"):
         g, b, l = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         check(lib().met2_plan_launch_info(self._h, METHODS[method], C.byref(g), C.byref(b), C.byref(l)))
