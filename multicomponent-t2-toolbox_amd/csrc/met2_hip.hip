@@ -484,14 +484,18 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
                 const double SSE = sse_of<NB>(S, st, b, lane);
                 const double target = A.x2_factor * SSE;
                 int flag;
+                double last_x = -1.0, last_sse = 0.0;
                 double lam = fminbound_dev([&](double x) {
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     double SSEr = sse_of<NB>(S, st, b, lane);
+                    last_x = x; last_sse = SSEr;
                     return fabs(SSEr - target) / SSE;
                 }, 0.0, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
-                regv = sse_of<NB>(S, st, b, lane) / SSE;          // k_est (motor:141-143)
+                // algorithms.py:220 solves once more at reg_opt; when Brent's last evaluation was at reg_opt the
+                // state already holds that solution (the solve is deterministic), so it is not repeated
+                if (lam != last_x) { nnls_solve_warm<NB>(S, bd, st, lam, true, lane); last_sse = sse_of<NB>(S, st, b, lane); }
+                regv = last_sse / SSE;                            // k_est (motor:141-143)
                 lamv = lam;
             } else if (METHOD == MET2_LCURVE) {
                 // algorithms.py:88-113
@@ -844,7 +848,12 @@ static int fast_kmax(const met2_plan *p, int method)
 {
     if (method == MET2_BAYESREG || method == MET2_GCV || method >= 10) return 0;
     if (const char *e = getenv("MET2_KMAX")) { int kk = atoi(e); return (kk >= 8 && kk < p->n_t2) ? kk : 0; }
-    const int k = (4 * p->n_t2 + 4) / 5;      // ceil(0.8 n)
+    // the largest capacity that still lets 16 waves share the LDS, but not below 0.8 n
+    // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M)
+    int k16 = 8;
+    while (16 * sizeof(double) * (size_t)((k16 + 1) * (k16 + 2) / 2) <= 160 * 1024 - 64) ++k16;
+    int k = (4 * p->n_t2 + 4) / 5;
+    if (k16 > k) k = k16;
     return k < p->n_t2 ? k : 0;
 }
 

@@ -429,9 +429,16 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
     if (warm && st.k > 0 && !nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
     for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows) break;
-        if (st.k >= S.kmax) { st.itmax_hit |= 2; break; }   // capacity of the fast path: the voxel is redone with kmax = n
         double w[NB];
         dual<NB>(S, bd, st, lam, lane, w);
+        if (st.k >= S.kmax) {
+            // capacity of the fast path reached: if a variable still wants to enter, the voxel is redone with kmax = n
+            double vmax = -1.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) vmax = fmax(vmax, ((lane + 64 * b < n) && !((st.P[b] >> lane) & 1ull)) ? w[b] : -1.0);
+            if (wave_max(vmax) > 0.0) st.itmax_hit |= 2;
+            break;
+        }
         // entering variable: largest positive dual among Z; rejected candidates are skipped
         u64 rejected[NB];
 #pragma unroll
