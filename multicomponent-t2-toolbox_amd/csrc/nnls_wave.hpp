@@ -160,32 +160,45 @@ __device__ __forceinline__ void givens(double a, double b, double &c, double &s,
     } else { sig = 0.0; c = 0.0; s = 1.0; }
 }
 
-// back substitution R z = y ; z position-indexed
+// back substitution R z = y ; z position-indexed.
+// The column loop is unrolled by two with two named prefetch registers: the LDS read issued in one step is
+// consumed a full step later, so the compiler can wait with lgkmcnt(1) instead of draining the read it has
+// just issued (a single rotating register forces lgkmcnt(0) in front of every FMA).
 template <int NB>
 __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<NB> &st, int lane, double (&z)[NB])
 {
     const int k = st.k;
-    double y[NB], rv[NB];
+    double y[NB], ra[NB], rb[NB];
     int rbl[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
         y[b] = st.y[b];
         rbl[b] = row_base(pl, S.kmax);
-        rv[b] = (k > 0 && pl < k - 1) ? S.R[rbl[b] + (k - 1)] : 0.0;
+        ra[b] = (k > 0 && pl < k - 1) ? S.R[rbl[b] + (k - 1)] : 0.0;     // column k-1
+        rb[b] = 0.0;
     }
-    for (int c = k - 1; c >= 0; --c) {
-        double rvn[NB];
+    int c = k - 1;
+    for (; c >= 1; c -= 2) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int pl = lane + 64 * b;
-            rvn[b] = (c > 0 && pl < c - 1) ? S.R[rbl[b] + (c - 1)] : 0.0;   // prefetch next column
+        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rb[b] = (pl < c - 1) ? S.R[rbl[b] + (c - 1)] : 0.0; }   // column c-1
+        {
+            double t = (NB == 2 && (c >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
+            double s = bcast(t, c & 63);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) y[b] = fma(-ra[b], s, y[b]);        // positions >= c are final
         }
-        double t = (NB == 2 && (c >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
-        double s = bcast(t, c & 63);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { y[b] = fma(-rv[b], s, y[b]); rv[b] = rvn[b]; }   // positions >= c are final
+        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; ra[b] = (c >= 2 && pl < c - 2) ? S.R[rbl[b] + (c - 2)] : 0.0; }   // column c-2
+        {
+            const int c1 = c - 1;
+            double t = (NB == 2 && (c1 >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
+            double s = bcast(t, c1 & 63);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) y[b] = fma(-rb[b], s, y[b]);
+        }
     }
+    // c == 0 needs no update (nothing lies above row 0's diagonal entry); c == -1: done
 #pragma unroll
     for (int b = 0; b < NB; ++b) z[b] = (lane + 64 * b < k) ? y[b] * st.rinv[b] : 0.0;
 }
@@ -284,21 +297,35 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
         const int pl = lane + 64 * b;
         double gg = gatherN<NB>(gb, st.ord[b]);                          // position-indexed G[ord_p][t]
         g[b] = (pl < k) ? gg : 0.0;
-        rv[b] = (k > 0 && pl > 0 && pl < k) ? S.R[row_base(0, kmax) + pl] : 0.0;
+        rv[b] = (k > 0 && pl > 0 && pl < k) ? S.R[row_base(0, kmax) + pl] : 0.0;      // row 0
     }
-    // forward substitution R^T r = g
-    for (int i = 0; i < k; ++i) {
-        double rvn[NB];
-        const int rbn = row_base(i + 1, kmax);
+    // forward substitution R^T r = g, unrolled by two with two prefetch registers (see back_subst)
+    {
+        double rw[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int pl = lane + 64 * b;
-            rvn[b] = (i + 1 < k && pl > i + 1 && pl < k) ? S.R[rbn + pl] : 0.0;
+        for (int b = 0; b < NB; ++b) rw[b] = 0.0;
+        int i = 0;
+        for (; i + 1 < k; i += 2) {
+            const int rb1 = row_base(i + 1, kmax), rb2 = row_base(i + 2, kmax);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rw[b] = (pl > i + 1 && pl < k) ? S.R[rb1 + pl] : 0.0; }   // row i+1
+            {
+                double tt = (NB == 2 && (i >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
+                double s = bcast(tt, i & 63);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) g[b] = fma(-rv[b], s, g[b]);      // positions <= i are final
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rv[b] = (i + 2 < k && pl > i + 2 && pl < k) ? S.R[rb2 + pl] : 0.0; }   // row i+2
+            {
+                const int i1 = i + 1;
+                double tt = (NB == 2 && (i1 >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
+                double s = bcast(tt, i1 & 63);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) g[b] = fma(-rw[b], s, g[b]);
+            }
         }
-        double tt = (NB == 2 && (i >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
-        double s = bcast(tt, i & 63);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { g[b] = fma(-rv[b], s, g[b]); rv[b] = rvn[b]; }   // positions <= i are final
+        // an odd last step i == k-1 updates nobody (no position lies beyond k-1)
     }
     double r[NB], rr = 0.0, ry = 0.0;
 #pragma unroll
