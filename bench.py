@@ -85,6 +85,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # MET2_BENCH_SHARE_GPU=1 (+ MET2_DIST_BACKEND=gloo) rehearses the N>1 code path on a one-GPU box: every
+    # rank uses cuda:0 and the collective runs over gloo on host copies.  Never set for measurements.
+    share = os.environ.get("MET2_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -118,6 +123,8 @@ def main():
     def _gather(maps):
         nonlocal gather_bufs
         import torch.distributed as dist
+        if dist.get_backend() == "gloo":
+            maps = maps.cpu()
         if rank == 0 and gather_bufs is None:
             gather_bufs = [torch.empty_like(maps) for _ in range(world)]
         dist.gather(maps, gather_bufs if rank == 0 else None, dst=0)
@@ -142,7 +149,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
