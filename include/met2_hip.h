@@ -149,6 +149,18 @@ int met2_fit(met2_plan *plan, int32_t method, int64_t nvox, const double *data, 
 int met2_fa_bruteforce(met2_plan *plan, int64_t nvox, const double *data, const uint8_t *mask,
                        double *fa_index, double *km, double *resid, void *stream);
 
+/* flip_angle_algorithms/fa_estimation.py:54-59, the selection step of the spline FA method (the CLI default,
+ * run_real_data_script.py:34): given the plain-NNLS residual norms on a coarse FA grid (`resid` from
+ * met2_fa_bruteforce on a plan built with the coarse grid, motor:237-238), interpolate them with a cubic
+ * spline (scipy interp1d(kind='cubic')), minimise over [90, 180] with the bounded Brent of
+ * scipy minimize_scalar(method='Bounded') and snap to the fine grid.  alpha_lr [n_lr] and alpha_hr [n_hr] are
+ * host arrays; resid [nvox][n_lr], data [nvox][n_te], mask are DEVICE pointers (data/mask only gate voxels,
+ * fa_estimation.py:45); out fa_index [nvox] float64 index into alpha_hr, xmin [nvox] the continuous minimiser
+ * (may be NULL).  Blocking. */
+int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
+                          int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
+                          double *fa_index, double *xmin, void *stream);
+
 /* motor:443-472 alone (fsol already on the device). */
 int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps,
                  void *stream);

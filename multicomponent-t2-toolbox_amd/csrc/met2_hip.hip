@@ -692,6 +692,62 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// spline flip-angle selection (flip_angle_algorithms/fa_estimation.py:54-59): cubic (not-a-knot)
+// interpolation of the coarse-grid NNLS residuals, bounded Brent over [90, 180] (scipy
+// minimize_scalar(method='Bounded'): xatol 1e-5, maxiter 500), snap to the fine FA grid.
+// One thread per voxel; the residuals come from fa_kernel on the coarse dictionary.
+// ------------------------------------------------------------------------------------------
+#define MET2_MAX_LR 32
+struct SplineArgs {
+    int nlr, nhr, nte;
+    const double *alpha_lr;   // [nlr] device
+    const double *W;          // [nlr][nlr] device: knot slopes = W y
+    const double *alpha_hr;   // [nhr] device
+    const double *resid;      // [nvox][nlr]
+    const double *data;       // [nvox][nte]
+    const uint8_t *mask;
+    double *fa_index, *xmin;
+    int64_t nvox;
+};
+
+__device__ __forceinline__ double spline_eval_dev(int n, const double *x, const double *y, const double *s, double xx)
+{
+    int i = 0;
+    while (i < n - 2 && xx >= x[i + 1]) ++i;
+    const double h = x[i + 1] - x[i], t = (xx - x[i]) / h;
+    const double h00 = (1.0 + 2.0 * t) * (1.0 - t) * (1.0 - t), h10 = t * (1.0 - t) * (1.0 - t);
+    const double h01 = t * t * (3.0 - 2.0 * t), h11 = t * t * (t - 1.0);
+    return h00 * y[i] + h10 * h * s[i] + h01 * y[i + 1] + h11 * h * s[i + 1];
+}
+
+__global__ __launch_bounds__(128) void fa_spline_kernel(SplineArgs A)
+{
+    __shared__ double sx[MET2_MAX_LR];
+    for (int i = threadIdx.x; i < A.nlr; i += blockDim.x) sx[i] = A.alpha_lr[i];
+    __syncthreads();
+    const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (v >= A.nvox) return;
+    double sum = 0.0;
+    for (int e = 0; e < A.nte; ++e) sum += A.data[(size_t)v * A.nte + e];
+    const bool mk = A.mask ? (A.mask[v] != 0) : true;
+    if (!(mk && sum > 0.0)) { A.fa_index[v] = 0.0; if (A.xmin) A.xmin[v] = 0.0; return; }
+    double y[MET2_MAX_LR], s[MET2_MAX_LR];
+    const int n = A.nlr;
+    for (int i = 0; i < n; ++i) y[i] = A.resid[(size_t)v * n + i];
+    for (int i = 0; i < n; ++i) {
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t = fma(A.W[i * n + j], y[j], t);
+        s[i] = t;
+    }
+    int flag;
+    const double xs = fminbound_dev([&](double x) { return spline_eval_dev(n, sx, y, s, x); }, 90.0, 180.0, 1e-5, 500, flag);
+    int best = 0; double dbest = fabs(A.alpha_hr[0] - xs);            // np.argmin(|alpha - x|): first minimum
+    for (int a = 1; a < A.nhr; ++a) { double d = fabs(A.alpha_hr[a] - xs); if (d < dbest) { dbest = d; best = a; } }
+    A.fa_index[v] = (double)best;
+    if (A.xmin) A.xmin[v] = xs;
+}
+
 // zeros for gated-out voxels (motor:115-117) and the metrics an all-zero spectrum gets at
 // motor:448-468 when mask > 0 (T2_M = T2_IE = exp(0) = 1, TWC = 1e-16)
 __global__ __launch_bounds__(256) void finalize_unfitted_kernel(int64_t nvox, int n, int m, const int *__restrict__ key,
@@ -894,6 +950,83 @@ static int launch_method(int method, const FitArgs &A, const LaunchGeom &g, hipS
     }
 }
 
+
+// slope weights of the not-a-knot cubic spline: knot slopes = W y (the system depends on the knots only)
+static void spline_weights_host(int n, const double *x, std::vector<double> &W)
+{
+    std::vector<double> A((size_t)n * n, 0.0), Rm((size_t)n * n, 0.0);   // A s = Rm y
+    auto h = [&](int i) { return x[i + 1] - x[i]; };
+    {   // not-a-knot at x[1]
+        const double h0 = h(0), h1 = h(1);
+        A[0] = h1; A[1] = h0 + h1;
+        // rhs = ((3h0+2h1) h1 d0 + h0^2 d1)/(h0+h1), d0 = (y1-y0)/h0, d1 = (y2-y1)/h1
+        const double c0 = (3.0 * h0 + 2.0 * h1) * h1 / (h0 + h1) / h0, c1 = h0 * h0 / (h0 + h1) / h1;
+        Rm[0] += -c0; Rm[1] += c0 - c1; Rm[2] += c1;
+    }
+    for (int i = 1; i < n - 1; ++i) {
+        const double hm = h(i - 1), hp = h(i);
+        A[(size_t)i * n + i - 1] = hp; A[(size_t)i * n + i] = 2.0 * (hm + hp); A[(size_t)i * n + i + 1] = hm;
+        const double cm = 3.0 * hp / hm, cp = 3.0 * hm / hp;               // rhs = 3 (hp dm + hm dp)
+        Rm[(size_t)i * n + i - 1] += -cm; Rm[(size_t)i * n + i] += cm - cp; Rm[(size_t)i * n + i + 1] += cp;
+    }
+    {   // not-a-knot at x[n-2]
+        const double ha = h(n - 3), hb = h(n - 2);
+        A[(size_t)(n - 1) * n + n - 2] = ha + hb; A[(size_t)(n - 1) * n + n - 1] = ha;
+        const double ca = hb * hb / (ha + hb) / ha, cb = (2.0 * ha + 3.0 * hb) * ha / (ha + hb) / hb;
+        Rm[(size_t)(n - 1) * n + n - 3] += -ca; Rm[(size_t)(n - 1) * n + n - 2] += ca - cb; Rm[(size_t)(n - 1) * n + n - 1] += cb;
+    }
+    // W = A^-1 Rm by Gaussian elimination with partial pivoting on [A | Rm]
+    for (int c = 0; c < n; ++c) {
+        int p = c; double mx = fabs(A[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; ++r) if (fabs(A[(size_t)r * n + c]) > mx) { mx = fabs(A[(size_t)r * n + c]); p = r; }
+        if (p != c) for (int j = 0; j < n; ++j) { std::swap(A[(size_t)c * n + j], A[(size_t)p * n + j]); std::swap(Rm[(size_t)c * n + j], Rm[(size_t)p * n + j]); }
+        for (int r = c + 1; r < n; ++r) {
+            const double l = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+            if (l == 0.0) continue;
+            for (int j = c; j < n; ++j) A[(size_t)r * n + j] -= l * A[(size_t)c * n + j];
+            for (int j = 0; j < n; ++j) Rm[(size_t)r * n + j] -= l * Rm[(size_t)c * n + j];
+        }
+    }
+    W.assign((size_t)n * n, 0.0);
+    for (int c = n - 1; c >= 0; --c)
+        for (int j = 0; j < n; ++j) {
+            double t = Rm[(size_t)c * n + j];
+            for (int q = c + 1; q < n; ++q) t -= A[(size_t)c * n + q] * W[(size_t)q * n + j];
+            W[(size_t)c * n + j] = t / A[(size_t)c * n + c];
+        }
+}
+
+extern "C" int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
+                                     int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
+                                     double *fa_index, double *xmin, void *stream)
+{
+    if (!alpha_lr || !resid || !alpha_hr || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
+    if (n_lr < 4 || n_lr > MET2_MAX_LR) return fail(MET2_E_UNSUPPORTED, "coarse FA grid must have 4..32 points");
+    if (n_hr < 1 || n_te < 1) return fail(MET2_E_INVALID, "bad shape");
+    for (int i = 1; i < n_lr; ++i) if (!(alpha_lr[i] > alpha_lr[i - 1])) return fail(MET2_E_INVALID, "coarse FA grid must increase");
+    if (nvox <= 0) return MET2_OK;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<double> W;
+    spline_weights_host(n_lr, alpha_lr, W);
+    double *dbuf = nullptr;
+    const size_t nd = (size_t)n_lr + (size_t)n_lr * n_lr + (size_t)n_hr;
+    HIPCHK(hipMalloc(&dbuf, sizeof(double) * nd));
+    std::vector<double> hb(nd);
+    memcpy(hb.data(), alpha_lr, sizeof(double) * n_lr);
+    memcpy(hb.data() + n_lr, W.data(), sizeof(double) * n_lr * n_lr);
+    memcpy(hb.data() + n_lr + (size_t)n_lr * n_lr, alpha_hr, sizeof(double) * n_hr);
+    HIPCHK(hipMemcpyAsync(dbuf, hb.data(), sizeof(double) * nd, hipMemcpyHostToDevice, s));
+    SplineArgs A;
+    A.nlr = n_lr; A.nhr = n_hr; A.nte = n_te;
+    A.alpha_lr = dbuf; A.W = dbuf + n_lr; A.alpha_hr = dbuf + n_lr + (size_t)n_lr * n_lr;
+    A.resid = resid; A.data = data; A.mask = mask; A.fa_index = fa_index; A.xmin = xmin; A.nvox = nvox;
+    hipLaunchKernelGGL(fa_spline_kernel, dim3((unsigned)((nvox + 127) / 128)), dim3(128), 0, s, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(dbuf));
+    return MET2_OK;
+}
 
 extern "C" {
 

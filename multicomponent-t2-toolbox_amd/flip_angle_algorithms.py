@@ -41,3 +41,18 @@ def fitting_slice_FA_brute_force(mask_1d, data_1d, nx, Dic_3D, alpha_values):
     # M[0] <= 0 but sum > 0 keep their FA index and contribute no spectrum here.
     fsum = out["fsol"].sum(dim=0).cpu().numpy()
     return FA, np.where(fitted, idx, 0.0), np.where(fitted, km, 0.0), fsum
+
+
+def fitting_slice_FA_spline_method(Dic_3D_LR, Dic_3D, data_1d, mask_1d, alpha_values_spline, nx, alpha_values):
+    """fa_estimation.py:35-70 -> (FA[nx], FA_index[nx], KM[nx], sum of spectra)"""
+    plan_lr = plan_for(Dic_3D_LR)
+    plan = plan_for(Dic_3D)
+    data = np.ascontiguousarray(data_1d, dtype=np.float64)
+    dd = torch.as_tensor(data, device=plan.device)
+    mk = torch.as_tensor(np.asarray(mask_1d) > 0, device=plan.device)
+    fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd, mk)
+    idx = fa.cpu().numpy()
+    fitted = (np.asarray(mask_1d) > 0) & (data.sum(axis=1) > 0)
+    FA = np.where(fitted, np.asarray(alpha_values)[idx.astype(int)], 0.0)
+    out = plan.fit("NNLS", dd, fa_index=fa, mask=torch.as_tensor(fitted, device=plan.device), want_maps=False)
+    return FA, np.where(fitted, idx, 0.0), np.where(fitted, km.cpu().numpy(), 0.0), out["fsol"].sum(dim=0).cpu().numpy()

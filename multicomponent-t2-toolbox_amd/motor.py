@@ -69,8 +69,8 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
     negative values clipped to 0 (motor:279), Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms,
     T1 = 1000 ms, 91 flip angles for brute force.  Returns a dict with the driver's ten outputs."""
-    if FA_method != "brute-force" and fa_index is None:
-        raise NotImplementedError("only FA_method='brute-force' (or a given fa_index) is built; 'spline' is SURVEY.md §8f item 1")
+    if FA_method not in ("brute-force", "spline"):
+        raise ValueError("FA_method must be 'spline' or 'brute-force'")
     data = np.asarray(data, dtype=np.float64)
     vol_shape = data.shape[:-1]
     nt = data.shape[-1]
@@ -83,16 +83,24 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     Npc = 96 if reg_method == "T2SPARC" else 60
     T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=Npc, endpoint=True, base=10.0)
     T1s = 1000.0 * np.ones_like(T2s)
-    alpha_values = np.linspace(90.0, 180.0, 91)
+    spline = (FA_method == "spline") and fa_index is None
+    alpha_values = np.linspace(90.0, 180.0, 91 * 3 if FA_method == "spline" else 91)      # motor:231-244
+    alpha_values_spline = np.linspace(90.0, 180.0, 15)                                      # motor:237
     own = plan is None
+    plan_lr = None
     if own:
-        plan = Met2Plan(nt, Npc, 91, device=device, myelin_T2=myelin_T2)
+        plan = Met2Plan(nt, Npc, alpha_values.shape[0], device=device, myelin_T2=myelin_T2)
         plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
         plan.set_penalty("InvT2" if reg_method == "T2SPARC" else reg_matrix, T2s)   # run_real_data_script.py:91-93
     dev = plan.device
     dd = torch.as_tensor(d2, device=dev)
     mm = torch.as_tensor(m1, device=dev)
-    if fa_index is None:
+    if spline:
+        plan_lr = Met2Plan(nt, Npc, 15, device=device)
+        plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_values_spline, TR)
+        fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd, mm)
+        plan_lr.close()
+    elif fa_index is None:
         fa, km, _ = plan.fa_bruteforce(dd, mm)
     else:
         fa = torch.as_tensor(np.asarray(fa_index, dtype=np.float64).reshape(-1), device=dev)

@@ -41,6 +41,11 @@ class Met2Plan:
         opt.brent_maxfun = brent_maxfun
         self._h = C.c_void_p(0)
         check(lib().met2_plan_create(C.byref(self._h), self.n_te, self.n_t2, self.n_fa, C.byref(opt)))
+        # the reference's L-curve grid, bit for bit as numpy builds it (motor:248-251); the C default is the same
+        # grid through pow() and can differ in the last bit
+        lam = np.zeros(50)
+        lam[1:] = np.logspace(np.log10(1e-8), np.log10(10.0), num=49, endpoint=True, base=10.0)
+        self.set_lambda_grid(lam)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -162,6 +167,26 @@ class Met2Plan:
         with torch.cuda.device(dev):
             check(lib().met2_fa_bruteforce(self._h, nvox, _ptr(data), _ptr(mask), _ptr(fa), _ptr(km), _ptr(resid), self._stream()))
         return fa, km, resid
+
+    def fa_spline(self, plan_lr, alpha_lr, alpha_hr, data, mask=None, want_xmin=False):
+        """Spline FA method (fa_estimation.py:35-70): `plan_lr` holds the coarse-grid dictionary (15 flip angles in the
+        driver, motor:237-238), this plan the fine one (273).  Returns (fa_index into alpha_hr, km, xmin or None)."""
+        assert data.is_cuda and data.dtype == torch.float64 and data.shape[1] == self.n_te
+        data = data.contiguous()
+        nvox = data.shape[0]
+        dev = data.device
+        mk = None if mask is None else (mask != 0).to(device=dev, dtype=torch.uint8).contiguous()
+        _, _, resid = plan_lr.fa_bruteforce(data, mk, want_resid=True)
+        (al, pal), (ah, pah) = _h(alpha_lr), _h(alpha_hr)
+        fa = torch.empty((nvox,), dtype=torch.float64, device=dev)
+        xmin = torch.empty((nvox,), dtype=torch.float64, device=dev) if want_xmin else None
+        with torch.cuda.device(dev):
+            check(lib().met2_fa_spline_select(dev.index or 0, nvox, al.shape[0], pal, _ptr(resid), ah.shape[0], pah, self.n_te, _ptr(data),
+                                              _ptr(mk), _ptr(fa), _ptr(xmin), self._stream()))
+        # km = sum of the plain-NNLS spectrum at the selected flip angle (fa_estimation.py:61-64)
+        gate = (data.sum(dim=1) > 0) if mk is None else ((data.sum(dim=1) > 0) & (mk != 0))
+        out = self.fit("NNLS", data, fa_index=fa, mask=gate, want_sig=False, want_maps=False, want_status=False)
+        return fa, out["fsol"].sum(dim=1), xmin
 
     def metrics(self, fsol, mask=None):
         fsol = fsol.contiguous()

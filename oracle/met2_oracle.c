@@ -24,6 +24,8 @@
  *   motor/motor_recon_met2_real_data.py:113-162 -> met2o_fit_batch
  *   motor/motor_recon_met2_real_data.py:443-472 -> met2o_metrics
  *   flip_angle_algorithms/fa_estimation.py:74-90 -> met2o_fa_bruteforce
+ *   flip_angle_algorithms/fa_estimation.py:35-70 -> met2o_fa_spline (scipy interp1d(kind='cubic') =
+ *        not-a-knot cubic spline; scipy minimize_scalar(method='Bounded') = the same bounded Brent)
  */
 #include <math.h>
 #include <stdint.h>
@@ -902,6 +904,109 @@ MET2O_API void met2o_fa_bruteforce(int nte, int nt2, int nfa, const double *Dfa,
             if (fout) memcpy(fout + (size_t)v * nt2, f, sizeof(double) * nt2);
         }
         free(f); ws_free(W);
+    }
+}
+
+/* ------------------------------------------------------------------ spline FA (fa_estimation.py:35-70) */
+/* Not-a-knot cubic spline through (x_i, y_i), i < n (n >= 4), evaluated from its knot slopes (Hermite form).
+ * interp1d(kind='cubic') builds the same interpolant in B-spline form; the function is unique. */
+static void spline_slopes(int n, const double *x, const double *y, double *s, double *work /* 4n */)
+{
+    double *dl = work, *dd = work + n, *du = work + 2 * n, *rhs = work + 3 * n;
+    double h0 = x[1] - x[0], h1 = x[2] - x[1], d0 = (y[1] - y[0]) / h0, d1 = (y[2] - y[1]) / h1;
+    dd[0] = h1; du[0] = h0 + h1; dl[0] = 0.0;
+    rhs[0] = ((3.0 * h0 + 2.0 * h1) * h1 * d0 + h0 * h0 * d1) / (h0 + h1);
+    for (int i = 1; i < n - 1; ++i) {
+        double hm = x[i] - x[i - 1], hp = x[i + 1] - x[i];
+        double dm = (y[i] - y[i - 1]) / hm, dp = (y[i + 1] - y[i]) / hp;
+        dl[i] = hp; dd[i] = 2.0 * (hm + hp); du[i] = hm;
+        rhs[i] = 3.0 * (hp * dm + hm * dp);
+    }
+    double ha = x[n - 2] - x[n - 3], hb = x[n - 1] - x[n - 2];
+    double da = (y[n - 2] - y[n - 3]) / ha, db = (y[n - 1] - y[n - 2]) / hb;
+    dl[n - 1] = ha + hb; dd[n - 1] = ha; du[n - 1] = 0.0;
+    rhs[n - 1] = (hb * hb * da + (2.0 * ha + 3.0 * hb) * ha * db) / (ha + hb);
+    /* the first and last rows couple three unknowns: eliminate to tridiagonal form with dense Gaussian steps */
+    /* small n: solve the almost-tridiagonal system by dense elimination with partial pivoting */
+    double *A = (double *)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        if (i == 0) { A[0] = dd[0]; A[1] = du[0]; }
+        else if (i == n - 1) { A[(size_t)i * n + n - 2] = dl[i]; A[(size_t)i * n + n - 1] = dd[i]; }
+        else { A[(size_t)i * n + i - 1] = dl[i]; A[(size_t)i * n + i] = dd[i]; A[(size_t)i * n + i + 1] = du[i]; }
+        s[i] = rhs[i];
+    }
+    for (int c = 0; c < n; ++c) {
+        int p = c; double mx = fabs(A[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; ++r) if (fabs(A[(size_t)r * n + c]) > mx) { mx = fabs(A[(size_t)r * n + c]); p = r; }
+        if (p != c) { for (int j = 0; j < n; ++j) { double t = A[(size_t)c * n + j]; A[(size_t)c * n + j] = A[(size_t)p * n + j]; A[(size_t)p * n + j] = t; } double t = s[c]; s[c] = s[p]; s[p] = t; }
+        for (int r = c + 1; r < n; ++r) {
+            double l = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+            if (l != 0.0) { for (int j = c; j < n; ++j) A[(size_t)r * n + j] -= l * A[(size_t)c * n + j]; s[r] -= l * s[c]; }
+        }
+    }
+    for (int c = n - 1; c >= 0; --c) {
+        double t = s[c];
+        for (int j = c + 1; j < n; ++j) t -= A[(size_t)c * n + j] * s[j];
+        s[c] = t / A[(size_t)c * n + c];
+    }
+    free(A);
+}
+typedef struct { int n; const double *x, *y, *s; } spline_ctx;
+static double spline_eval(double xx, void *v)
+{
+    spline_ctx *c = (spline_ctx *)v;
+    int i = 0;
+    while (i < c->n - 2 && xx >= c->x[i + 1]) ++i;
+    double h = c->x[i + 1] - c->x[i], t = (xx - c->x[i]) / h;
+    double h00 = (1.0 + 2.0 * t) * (1.0 - t) * (1.0 - t), h10 = t * (1.0 - t) * (1.0 - t);
+    double h01 = t * t * (3.0 - 2.0 * t), h11 = t * t * (t - 1.0);
+    return h00 * c->y[i] + h10 * h * c->s[i] + h01 * c->y[i + 1] + h11 * h * c->s[i + 1];
+}
+/* slope weights W (n x n): slopes = W y (the system matrix depends on x only) */
+MET2O_API void met2o_spline_weights(int n, const double *x, double *W)
+{
+    double *y = (double *)calloc(n, sizeof(double)), *s = (double *)malloc(sizeof(double) * n), *work = (double *)malloc(sizeof(double) * 4 * n);
+    for (int j = 0; j < n; ++j) {
+        memset(y, 0, sizeof(double) * n); y[j] = 1.0;
+        spline_slopes(n, x, y, s, work);
+        for (int i = 0; i < n; ++i) W[(size_t)i * n + j] = s[i];
+    }
+    free(y); free(s); free(work);
+}
+/* fa_estimation.py:35-70 per voxel: residual norms of the plain NNLS over the coarse FA grid (Dlr), cubic
+ * interpolation, bounded minimisation over [alpha_lr[0], alpha_lr[nlr-1]], snap to the fine grid alpha_hr,
+ * km = sum of the NNLS spectrum at the snapped FA (Dhr).  Outputs: idx (float64), km, xmin (optional). */
+MET2O_API void met2o_fa_spline(int nte, int nt2, int nlr, const double *Dlr, const double *alpha_lr, int nhr, const double *Dhr,
+                               const double *alpha_hr, int64_t nvox, const double *data, const double *mask, double *idx,
+                               double *km, double *xmin, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        nnls_ws *W = ws_new(nte, nt2);
+        double *f = (double *)malloc(sizeof(double) * nt2);
+        double *res = (double *)malloc(sizeof(double) * nlr), *sl = (double *)malloc(sizeof(double) * nlr);
+        double *work = (double *)malloc(sizeof(double) * 4 * nlr);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t v = 0; v < nvox; ++v) {
+            const double *M = data + (size_t)v * nte;
+            idx[v] = 0.0; km[v] = 0.0; if (xmin) xmin[v] = 0.0;
+            double sum = 0.0; for (int e = 0; e < nte; ++e) sum += M[e];
+            if (!(mask[v] > 0.0) || !(sum > 0.0)) continue;
+            for (int a = 0; a < nlr; ++a) o_nnls_aug(W, Dlr + (size_t)a * nte * nt2, M, NULL, 0.0, nte, nt2, 0, f, &res[a]);
+            spline_slopes(nlr, alpha_lr, res, sl, work);
+            spline_ctx sc = { nlr, alpha_lr, res, sl };
+            double xs = o_fminbound(spline_eval, &sc, 90.0, 180.0, 1e-5, 500, NULL, NULL, NULL);
+            int best = 0; double dbest = fabs(alpha_hr[0] - xs);
+            for (int a = 1; a < nhr; ++a) { double d = fabs(alpha_hr[a] - xs); if (d < dbest) { dbest = d; best = a; } }
+            double rn;
+            o_nnls_aug(W, Dhr + (size_t)best * nte * nt2, M, NULL, 0.0, nte, nt2, 0, f, &rn);
+            double s = 0.0; for (int j = 0; j < nt2; ++j) s += f[j];
+            idx[v] = (double)best; km[v] = s; if (xmin) xmin[v] = xs;
+        }
+        free(f); free(res); free(sl); free(work); ws_free(W);
     }
 }
 

@@ -201,5 +201,23 @@ def compute_optimal_FA(M, Dic_3D, alpha_values):
     return i, alpha_values[i], km[0], sse[0], f[0]
 
 
+def fa_spline(D_lr_fa_major, alpha_lr, D_hr_fa_major, alpha_hr, data, mask, nthreads=1):
+    """fa_estimation.py:35-70 over a flat voxel list -> (idx, km, xmin)"""
+    Dl = _d(D_lr_fa_major); Dh = _d(D_hr_fa_major); al = _d(alpha_lr); ah = _d(alpha_hr)
+    nlr, nte, nt2 = Dl.shape
+    data = _d(data); nvox = data.shape[0]; mk = _d(mask)
+    idx = np.zeros(nvox); km = np.zeros(nvox); xm = np.zeros(nvox)
+    lib().met2o_fa_spline(nte, nt2, nlr, _p(Dl), _p(al), Dh.shape[0], _p(Dh), _p(ah), C.c_int64(nvox), _p(data), _p(mk), _p(idx), _p(km),
+                          _p(xm), int(nthreads))
+    return idx, km, xm
+
+
+def spline_weights(x):
+    x = _d(x); n = x.shape[0]
+    W = np.zeros((n, n))
+    lib().met2o_spline_weights(n, _p(x), _p(W))
+    return W
+
+
 def max_threads():
     return lib().met2o_max_threads()

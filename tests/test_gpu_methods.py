@@ -184,3 +184,37 @@ def test_driver_end_to_end_golden(pkg):
     for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
         scale = max(1.0, np.max(np.abs(g[name])))
         assert np.max(np.abs(res[name] - g[name])) / scale < TOL, name
+
+
+def test_spline_fa_and_driver_golden(pkg):
+    # spline FA estimation (fa_estimation.py:35-70) + L-curve/L1 + metrics, against the
+    # reference's own end-to-end run (spline is the CLI default, run_real_data_script.py:34)
+    import torch
+    from oracle import oracle
+    motor = importlib.import_module(PKG + ".motor")
+    faa = importlib.import_module(PKG + ".flip_angle_algorithms")
+    g = np.load(os.path.join(GOLDEN, "golden_motor_lcurve_l1_spline.npz"))
+    res = motor.recon_met2_arrays(g["data"], g["mask"], g["TE"], 3000.0, "L_curve", "L1", "spline", 40.0)
+    assert np.array_equal(res["FA"], g["FA"])
+    assert relmax(res["fsol_4D"], g["fsol_4D"]) < TOL
+    assert np.array_equal(res["reg_param"], g["reg_param"])
+    for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
+        assert np.max(np.abs(res[name] - g[name])) / max(1.0, np.max(np.abs(g[name]))) < TOL, name
+    # the per-row mirror against the oracle, including the continuous minimiser
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(60); T1s = 1000.0 * np.ones(60)
+    ah = np.linspace(90.0, 180.0, 273); al = np.linspace(90.0, 180.0, 15)
+    ph = pkg.Met2Plan(32, 60, 273); ph.build_dictionary_epg(T2s, T1s, 10.0, ah, 3000.0)
+    pl = pkg.Met2Plan(32, 60, 15); pl.build_dictionary_epg(T2s, T1s, 10.0, al, 3000.0)
+    data, fa_true, _ = synth.make_voxels(400, nte=32, seed=41, fa_values=ah, device="cuda")
+    mask = torch.ones(400, dtype=torch.uint8, device="cuda"); mask[3] = 0
+    fa, km, xmin = ph.fa_spline(pl, al, ah, data, mask, want_xmin=True)
+    Dh = np.ascontiguousarray(np.transpose(ph.get_dictionary(), (2, 0, 1)))
+    Dl = np.ascontiguousarray(np.transpose(pl.get_dictionary(), (2, 0, 1)))
+    idx, kmo, xm = oracle.fa_spline(Dl, al, Dh, ah, data.cpu().numpy(), mask.cpu().numpy().astype(float), nthreads=8)
+    assert np.allclose(xmin.cpu().numpy(), xm, rtol=1e-7, atol=1e-6)
+    assert np.mean(fa.cpu().numpy() == idx) > 0.995 and np.max(np.abs(fa.cpu().numpy() - idx)) <= 1
+    same = fa.cpu().numpy() == idx
+    assert np.allclose(km.cpu().numpy()[same], kmo[same], rtol=1e-6)
+    assert fa[3] == 0 and km[3] == 0
+    assert np.mean(np.abs(ah[fa.cpu().numpy().astype(int)] - ah[fa_true.cpu().numpy().astype(int)]) <= 3.0) > 0.7      # it does estimate the flip angle

@@ -83,6 +83,45 @@ def test_oracle_pipeline_vs_driver_golden(oracle, tag, meth, pen):
         assert np.allclose(maps[name].reshape(shp), g[name], rtol=1e-8, atol=1e-12), name
 
 
+def test_oracle_spline_pipeline_vs_driver_golden(oracle):
+    # spline FA (fa_estimation.py:35-70, the CLI default) -> L-curve/L1 -> metrics, against the reference's own run
+    g = np.load(os.path.join(GOLDEN, "golden_motor_lcurve_l1_spline.npz"))
+    data = g["data"]; mask = g["mask"]
+    shp = mask.shape; nt = data.shape[-1]
+    d2 = (data * (mask[..., None] != 0)).reshape(-1, nt)
+    d2 = np.where(d2 < 0, 0.0, d2)
+    m1 = (mask.reshape(-1) > 0).astype(float)
+    T2s = np.logspace(1, np.log10(2000.0), 60); T1s = 1000.0 * np.ones(60)
+    ah = np.linspace(90.0, 180.0, 273); al = np.linspace(90.0, 180.0, 15)
+    Dh = oracle.dictionary_fa_major(60, T2s, T1s, nt, 10.0, ah, 3000.0)
+    Dl = oracle.dictionary_fa_major(60, T2s, T1s, nt, 10.0, al, 3000.0)
+    idx, km, xm = oracle.fa_spline(Dl, al, Dh, ah, d2, m1, nthreads=4)
+    fitted = (m1 > 0) & (d2.sum(axis=1) > 0)
+    assert np.array_equal(np.where(fitted, ah[idx.astype(int)], 0.0).reshape(shp), g["FA"])
+    lam_grid = np.zeros(50); lam_grid[1:] = np.logspace(-8, 1, 49)
+    fs, sg, rg, st = oracle.fit_batch("L_curve", Dh, oracle.penalty(60, "L1"), d2, idx, m1, lambda_reg=lam_grid, nthreads=4)
+    assert relmax(fs.reshape(shp + (60,)), g["fsol_4D"]) < 1e-8
+    assert np.array_equal(rg.reshape(shp), g["reg_param"])
+    maps = oracle.metrics(fs, T2s, m1)
+    for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
+        assert np.allclose(maps[name].reshape(shp), g[name], rtol=1e-8, atol=1e-12), name
+
+
+def test_spline_weights_match_scipy(oracle):
+    # interp1d(kind='cubic') is the not-a-knot cubic spline: same interpolant from the slope form
+    from scipy.interpolate import interp1d
+    x = np.linspace(90.0, 180.0, 15)
+    rng = np.random.default_rng(3)
+    y = rng.uniform(0.5, 2.0, 15) + 0.002 * (x - 140.0) ** 2
+    s = oracle.spline_weights(x) @ y
+    f2 = interp1d(x, y, kind="cubic")
+    for xx in np.linspace(90.0, 180.0, 257):
+        i = min(np.searchsorted(x, xx, side="right") - 1, 13)
+        h = x[i + 1] - x[i]; t = (xx - x[i]) / h
+        v = (1 + 2 * t) * (1 - t) ** 2 * y[i] + t * (1 - t) ** 2 * h * s[i] + t * t * (3 - 2 * t) * y[i + 1] + t * t * (t - 1) * h * s[i + 1]
+        assert abs(v - float(f2(xx))) < 1e-12
+
+
 def test_metrics_edge_cases(oracle):
     # motor:448-468: masked-in but unfitted voxel -> fractions 0, T2_M = T2_IE = 1, TWC = 1e-16; masked-out -> 0
     T2s = np.logspace(1, np.log10(2000.0), 60)
