@@ -875,7 +875,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     g.np = n | 1;
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
-    if (method == MET2_GCV && (m + 1) * n > g.wave_doubles) g.wave_doubles = (m + 1) * n;   // E^T (k x (m+1)) for the Jacobi SVD
+    if (method == MET2_GCV && (m + 1) * (n + 2) > g.wave_doubles) g.wave_doubles = (m + 1) * (n + 2);   // E^T (k x (m+1)) + norms + rotation row
     // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
     // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
     // only ~k rows of B, so the fit kernel prefers the LDS for more resident waves per CU (measured on X2/L2:

@@ -122,9 +122,9 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // the singular values of G are the squared singular values of E and, for E = U S V^T,
 //   trace(Dr G^+ Dr^T) = sum_{kept i} (1 - U[m][i]^2).
 // E^T (k x (m+1)) is small in its column count whatever the support size: one-sided Jacobi on its
-// m+1 columns (lane = support row, NB slots), carrying only the last row of the accumulated
-// rotations.  Column norms are cached per lane and refreshed every sweep; pairs whose columns both sit
-// far below the cutoff are skipped.
+// m+1 columns in a round-robin ordering that rotates up to 16 (nTE=32) or 24 (nTE=48) disjoint pairs at once,
+// carrying only the last row of the accumulated rotations.  Column norms are cached in LDS and refreshed
+// every sweep; pairs whose columns both sit far below the cutoff are skipped.
 template <int NB>
 __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double x, double b,
                                                 int lane, int &overflow)
@@ -145,7 +145,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         l2 += inS[bb] ? ld * ld : 0.0;
     }
     if (k == 0) return NAN;
-    if (mm * k > S.rcap) { overflow = 1; return INFINITY; }
+    if (mm * k + 2 * mm > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
     // support list through LDS: rank-th support bin -> sp of the owner of row `rank`
     int *list = (int *)S.R;
@@ -162,6 +162,8 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     for (int bb = 0; bb < NB; ++bb) sp[bb] = (lane + 64 * bb < k) ? list[lane + 64 * bb] : 0;
     __builtin_amdgcn_wave_barrier();
     double *A = S.R;                                   // column-major k x (m+1): A[e*k + r] = E[e][s_r]
+    double *cn2 = A + mm * k;                          // [mm] squared column norms
+    double *wl = cn2 + mm;                             // [mm] last row of the accumulated rotations
     const double sc = sqrt(c);
     for (int e = 0; e < mm; ++e) {
 #pragma unroll
@@ -170,57 +172,73 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
             if (r < k) A[e * k + r] = (e < m) ? S.D[e * S.dstride + sp[bb]] : sc;
         }
     }
+    if (lane < mm) wl[lane] = (lane == m) ? 1.0 : 0.0;
     __builtin_amdgcn_wave_barrier();
-    double wl = (lane == m) ? 1.0 : 0.0;               // lane e: last row of the accumulated rotations
-    double cn2 = 0.0;                                  // lane e: ||column e||^2
+    // Round-robin ("tournament") ordering: N = mm rounded up to even players, N-1 rounds of N/2 disjoint column
+    // pairs; with mm odd the fixed player is a dummy and its pair is skipped.  Every pair gets LP lanes: the
+    // lanes of a pair split the k rows, partial inner products meet through LP-wide xor shuffles, and the
+    // rotation parameters (the expensive sqrt/div chain) are computed once per round for all pairs at once.
+    const int odd = mm & 1;
+    const int N = mm + odd, nreal = N / 2 - odd;
+    const int LP = (nreal <= 16) ? 4 : (nreal <= 32 ? 2 : 1);
+    const int pi = lane / LP, sub = lane - pi * LP;
+    const bool mine = pi < nreal;
+    const int ti = pi + odd;                           // pair index inside the round (0 = the fixed player's pair)
     for (int sweep = 0; sweep < 30; ++sweep) {
         // refresh the cached column norms (lane e walks its own column)
-        cn2 = 0.0;
-        for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; cn2 = fma(v, v, cn2); }
-        const double big = wave_max(lane < mm ? cn2 : 0.0);
+        {
+            double t2 = 0.0;
+            for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; t2 = fma(v, v, t2); }
+            if (lane < mm) cn2[lane] = t2;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double big = wave_max(lane < mm ? cn2[lane] : 0.0);
         const double floor2 = 1e-6 * (2.220446049250313e-16 * (double)k * big);   // far below lstsq's cutoff on sigma^2
-        const double noise = 4.0 * 2.220446049250313e-16 * sqrt(big * (double)k);
-        int rotated = 0;
-        for (int p = 0; p < mm - 1; ++p)
-            for (int q = p + 1; q < mm; ++q) {
-                const double alpha = bcast(cn2, p), beta = bcast(cn2, q);
-                if (alpha < floor2 && beta < floor2) continue;
-                double ap[NB], aq[NB], gamma = 0.0;
-#pragma unroll
-                for (int bb = 0; bb < NB; ++bb) {
-                    const int r = lane + 64 * bb;
-                    ap[bb] = (r < k) ? A[p * k + r] : 0.0;
-                    aq[bb] = (r < k) ? A[q * k + r] : 0.0;
-                    gamma = fma(ap[bb], aq[bb], gamma);
+        const double noise2 = 16.0 * 4.930380657631324e-32 * big * (double)k;      // (4 eps)^2 * big * k
+        u64 rotated = 0ull;
+        for (int rd = 0; rd < N - 1; ++rd) {
+            int ca, cb;
+            if (ti == 0) { ca = rd; cb = N - 1; }
+            else { ca = (rd + ti) % (N - 1); cb = (rd - ti + (N - 1)) % (N - 1); }
+            if (ca > cb) { int t = ca; ca = cb; cb = t; }
+            const double alpha = mine ? cn2[ca] : 0.0, beta = mine ? cn2[cb] : 0.0;
+            double gamma = 0.0;
+            if (mine) for (int r = sub; r < k; r += LP) gamma = fma(A[ca * k + r], A[cb * k + r], gamma);
+            if (LP >= 2) gamma += __shfl_xor(gamma, 1);
+            if (LP >= 4) gamma += __shfl_xor(gamma, 2);
+            const double g2 = gamma * gamma;
+            // converged pair: orthogonal to working precision, or the inner product is at the level of the absolute
+            // rounding noise (eps * sqrt(big) per entry) that cancellation left in small columns
+            const bool rot = mine && !(alpha < floor2 && beta < floor2) && (g2 > 1e-30 * alpha * beta) && (g2 > noise2 * fmax(alpha, beta));
+            rotated |= ballot(rot);
+            const double a = beta - alpha, g = 2.0 * gamma;
+            const double hyp = sqrt(a * a + g * g);
+            const double t = (a >= 0.0) ? g / (a + hyp) : g / (a - hyp);     // tan of the rotation angle, |t| <= 1
+            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+            if (rot) {
+                for (int r = sub; r < k; r += LP) {
+                    const double ap = A[ca * k + r], aq = A[cb * k + r];
+                    A[ca * k + r] = cs * ap - sn * aq;
+                    A[cb * k + r] = sn * ap + cs * aq;
                 }
-                gamma = wave_sum(gamma);
-                // converged pair: orthogonal to working precision, or the inner product is at the level of the
-                // absolute rounding noise (eps * sqrt(big) per entry) that cancellation left in small columns
-                if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta) || fabs(gamma) <= noise * sqrt(fmax(alpha, beta))) continue;
-                rotated += 1;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                const double wp = bcast(wl, p), wq = bcast(wl, q);
-#pragma unroll
-                for (int bb = 0; bb < NB; ++bb) {
-                    const int r = lane + 64 * bb;
-                    if (r < k) { A[p * k + r] = cs * ap[bb] - sn * aq[bb]; A[q * k + r] = sn * ap[bb] + cs * aq[bb]; }
+                if (sub == 0) {
+                    const double wp = wl[ca], wq = wl[cb];
+                    wl[ca] = cs * wp - sn * wq; wl[cb] = sn * wp + cs * wq;
+                    cn2[ca] = alpha - t * gamma; cn2[cb] = beta + t * gamma;
                 }
-                if (lane == p) { wl = cs * wp - sn * wq; cn2 = alpha - t * gamma; }
-                if (lane == q) { wl = sn * wp + cs * wq; cn2 = beta + t * gamma; }
             }
+            __builtin_amdgcn_wave_barrier();
+        }
         MET2_STAT(6, sweep + 1);
-        MET2_STAT(7, rotated);
         if (!rotated) break;
     }
-    __builtin_amdgcn_wave_barrier();
-    cn2 = 0.0;
-    for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; cn2 = fma(v, v, cn2); }
-    const double smax = wave_max(lane < mm ? cn2 : 0.0);                 // singular values of G = sigma(E)^2
+    double t2 = 0.0;
+    for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; t2 = fma(v, v, t2); }
+    const double smax = wave_max(lane < mm ? t2 : 0.0);                  // singular values of G = sigma(E)^2
     const double cut = 2.220446049250313e-16 * (double)k * smax;
-    const bool keep = (lane < mm) && (cn2 > cut);
-    const double tr = wave_sum(keep ? (1.0 - wl * wl) : 0.0);
+    const bool keep = (lane < mm) && (t2 > cut);
+    const double wv = (lane < mm) ? wl[lane] : 0.0;
+    const double tr = wave_sum(keep ? (1.0 - wv * wv) : 0.0);
     const double num = (1.0 / m) * rn2;
     const double den = (1.0 / m) * ((double)m - tr);
     return log(num / (den * den));
