@@ -1272,7 +1272,9 @@ int met2_plan_set_lambda_grid(met2_plan *p, const double *lam, int32_t n)
 int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, const double *fa_index, const uint8_t *mask,
              double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, void *stream)
 {
-    if (!p || !data || !fsol || !reg) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    if (nvox == 0) return MET2_OK;                       // empty voxel list: nothing to do (pointers may be NULL)
+    if (!data || !fsol || !reg) return fail(MET2_E_INVALID, "NULL argument");
     if (nvox < 0 || nvox > 0x7fffffff) return fail(MET2_E_INVALID, "nvox out of range");
     if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
     if (method != MET2_NNLS && !p->have_pen) return fail(MET2_E_STATE, "no penalty matrix set");

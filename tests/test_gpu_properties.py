@@ -1,0 +1,141 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full configs[1] size, and the
+edge cases of the boundary (empty / fully gated / non-finite input, bad FA index, unsupported shapes)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PKG = "multicomponent-t2-toolbox_amd"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available()
+    return importlib.import_module(PKG)
+
+
+@pytest.fixture(scope="module")
+def big(pkg):
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2 = 32, 60
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty("L2")
+    nvox = 128 * 128 * 64
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=20260102, device="cuda")
+    out = plan.fit("X2", data, want_lambda=True)
+    torch.cuda.synchronize()
+    return plan, data, out
+
+
+def test_full_size_properties(pkg, big):
+    # configs[1]: 1 048 576 voxels, X2/L2
+    import torch
+    plan, data, out = big
+    fs, sg, maps, st = out["fsol"], out["sig"], out["maps"], out["status"]
+    assert torch.isfinite(fs).all() and (fs >= 0).all()
+    assert (st & 1).all() and not (st & (4 | 8 | 32)).any()
+    # Est_Signal is the dictionary applied to the spectrum (motor:155)
+    D = torch.as_tensor(plan.get_dictionary()[:, :, 0], device="cuda")
+    ref = fs @ D.T
+    assert (sg - ref).abs().max() / ref.abs().max() < 1e-12
+    # the three windows partition the T2 grid: fractions sum to one; T2 means lie inside their windows
+    tot = maps[0] + maps[1] + maps[2]
+    assert (tot - 1.0).abs().max() < 1e-12
+    assert (maps[5] - (fs.sum(dim=1) + 1e-16)).abs().max() / maps[5].max() < 1e-13
+    has_m = maps[0] > 1e-6            # (the 1e-16 in the denominator of motor:462 pulls T2_M towards 1 for tiny MWF)
+    assert (maps[3][has_m] >= 10.0 * (1 - 1e-6)).all() and (maps[3][has_m] <= 40.0).all()
+    # X2 hits its target chi^2 ratio (algorithms.py:231) within the Brent tolerance on all but the lambda -> 0 end points
+    kest = out["reg"]
+    assert ((kest - 1.02).abs() < 2e-3).double().mean() > 0.99
+    assert (out["lam"] >= 0).all() and (out["lam"] <= 10).all()
+    # the fit explains the data at the noise level
+    rel = ((sg - data) ** 2).sum(dim=1).sqrt() / (data ** 2).sum(dim=1).sqrt()
+    assert rel.median() < 0.03
+
+
+def test_scale_equivariance_and_order_independence(pkg, big):
+    # every voxel is normalised by its first echo (motor:129-132): scaling by 2 is exact in binary, so the outputs
+    # scale bit for bit; and a voxel's result cannot depend on where it sits in the volume or on scheduling
+    import torch
+    plan, data, out = big
+    n = 200_000
+    sub = data[:n]
+    o2 = plan.fit("X2", 2.0 * sub)
+    assert torch.equal(o2["fsol"], 2.0 * out["fsol"][:n])
+    assert torch.equal(o2["reg"], out["reg"][:n])
+    assert torch.equal(o2["maps"][0], out["maps"][0][:n])
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    o3 = plan.fit("X2", sub[perm])
+    assert torch.equal(o3["fsol"], out["fsol"][:n][perm])
+    assert torch.equal(o3["sig"], out["sig"][:n][perm])
+
+
+def test_nnls_kkt_full_size(pkg, big):
+    # Lawson-Hanson's optimality conditions, implementation-independent: x >= 0, dual <= tol on the active set,
+    # |dual| <= tol on the passive set (SURVEY.md §4 test plan item 2)
+    import torch
+    plan, data, _ = big
+    n = 262_144
+    out = plan.fit("NNLS", data[:n])
+    D = torch.as_tensor(plan.get_dictionary()[:, :, 0], device="cuda")
+    x = out["fsol"]
+    w = (data[:n] - x @ D.T) @ D                      # D^T (b - D x)
+    scale = (data[:n] @ D).abs().max(dim=1).values.unsqueeze(1)
+    assert (x >= 0).all()
+    assert (w / scale).max() < 1e-9
+    assert ((w / scale).abs() * (x > 0)).max() < 1e-9
+
+
+def test_edge_cases(pkg):
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(60); T1s = 1000.0 * np.ones(60)
+    plan = pkg.Met2Plan(32, 60, 3)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, np.array([120.0, 150.0, 180.0]), 3000.0).set_penalty("I")
+    # empty input
+    out = plan.fit("X2", torch.empty((0, 32), dtype=torch.float64, device="cuda"))
+    assert out["fsol"].shape == (0, 60)
+    data, _, _ = synth.make_voxels(64, nte=32, seed=9, device="cuda")
+    # everything gated out: zeros, status 0, all-zero-spectrum metrics where mask != 0 (motor:448-468)
+    out = plan.fit("X2", data, mask=torch.zeros(64, device="cuda"))
+    assert not out["fsol"].any() and not out["sig"].any() and not out["status"].any() and not out["maps"].any()
+    z = torch.zeros_like(data)
+    out = plan.fit("X2", z)
+    assert not out["fsol"].any() and (out["maps"][3] == 1.0).all() and (out["maps"][4] == 1.0).all() and (out["maps"][5] == 1e-16).all()
+    # non-finite voxel: flagged, zeros, neighbours untouched (the reference would raise ValueError for the whole run)
+    d2 = data.clone(); d2[7, 3] = float("nan"); d2[9, 0] = float("inf")
+    o_ref = plan.fit("X2", data)
+    out = plan.fit("X2", d2)
+    st = out["status"].cpu().numpy()
+    assert st[7] == 4 and st[9] == 4 and not out["fsol"][7].any() and not out["fsol"][9].any()
+    keep = np.ones(64, bool); keep[[7, 9]] = False
+    assert torch.equal(out["fsol"][torch.as_tensor(keep)], o_ref["fsol"][torch.as_tensor(keep)])
+    # per-voxel FA index: each voxel uses its own kernel; an index outside the dictionary is an error
+    fa = torch.tensor([0.0, 1.0, 2.0] * 21 + [1.0], device="cuda", dtype=torch.float64)
+    out = plan.fit("X2", data, fa_index=fa)
+    for f in (0, 1, 2):
+        sel = fa == f
+        solo = plan.fit("X2", data[sel], fa_index=fa[sel])
+        assert torch.equal(solo["fsol"], out["fsol"][sel])
+    with pytest.raises(pkg.Met2Error):
+        plan.fit("X2", data, fa_index=torch.full((64,), 3.0, device="cuda", dtype=torch.float64))
+    # unsupported shapes / penalties fail loudly
+    with pytest.raises(pkg.Met2Error):
+        pkg.Met2Plan(32, 129, 1)
+    with pytest.raises(pkg.Met2Error):
+        pkg.Met2Plan(64, 60, 1)
+    Lw = np.eye(60); Lw[0, 5] = 1.0
+    with pytest.raises(pkg.Met2Error):
+        plan.set_penalty(Lw)
+    with pytest.raises(pkg.Met2Error):
+        pkg.Met2Plan(32, 60, 1).fit("X2", data)            # no dictionary yet
+    # T2SPARC's Npc = 96 (motor:207-213) runs through the two-bins-per-lane kernels
+    p96 = pkg.Met2Plan(32, 96, 1)
+    T96 = synth.t2_grid(96)
+    p96.build_dictionary_epg(T96, 1000.0 * np.ones(96), 10.0, np.array([150.0]), 3000.0).set_penalty("InvT2", T96)
+    o96 = p96.fit("T2SPARC", data)
+    assert (o96["reg"] == 1.8).all() and (o96["fsol"] >= 0).all() and torch.isfinite(o96["fsol"]).all()
