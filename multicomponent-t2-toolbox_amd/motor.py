@@ -118,3 +118,36 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     if own:
         plan.close()
     return res
+
+
+def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR, reg_method, reg_matrix, denoise, FA_method,
+                     FA_smooth, myelin_T2, num_cores=-1, device=0):
+    """Drop-in for motor_recon_met2 (motor:165-506) with the reference's on-disk contract: NIfTI in
+    (data [nx,ny,nz,nt], mask [nx,ny,nz]), ten NIfTI volumes out (MWF, IEWF, FWF, T2_M, T2_IE, TWC, FA, fsol_4D,
+    Est_Signal, reg_param .nii.gz at path_to_save_data, motor:475-503).  `num_cores` is accepted and ignored (one
+    process drives the GPU).  Not reproduced: TV / NESMA denoising (motor:293-334; denoise must be 'None') and the
+    mean-spectrum PNG of motor:377-424."""
+    from . import nifti
+    if denoise not in ("None", None, "none"):
+        raise NotImplementedError("denoise=%r is not built (motor:293-334 is outside the hot path)" % (denoise,))
+    img = nifti.load(path_to_data)
+    data = img.get_fdata().astype(np.float64, copy=False)
+    mask = nifti.load(path_to_mask).get_fdata().astype(np.int64)
+    if data.ndim != 4 or mask.shape != data.shape[:3]:
+        raise ValueError("data must be 4-D and mask must match its first three dimensions")
+    fa_index = None
+    if FA_smooth == "yes":
+        # motor:337-343: the flip angle is estimated on Gaussian-smoothed data (sigma 2 voxels), the spectra on the raw data
+        import scipy.ndimage as filt
+        dm = data * (mask[..., None] != 0)
+        dm[dm < 0.0] = 0.0
+        sm = np.stack([filt.gaussian_filter(dm[..., c], 2.0, 0) for c in range(dm.shape[-1])], axis=-1)
+        pre = recon_met2_arrays(sm, mask, TE_array, TR, "NNLS", reg_matrix, FA_method, myelin_T2, device=device)
+        fa_index = pre["FA_index"]
+    res = recon_met2_arrays(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index=fa_index, device=device)
+    if fa_index is not None:
+        n_alpha = 91 * 3 if FA_method == "spline" else 91
+        res["FA"] = np.where(mask > 0, np.linspace(90.0, 180.0, n_alpha)[np.asarray(fa_index).astype(int)], 0.0)
+    for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
+        nifti.save(nifti.NiftiImage(res[name], img.affine), path_to_save_data + name + ".nii.gz")
+    return res

@@ -218,3 +218,30 @@ def test_spline_fa_and_driver_golden(pkg):
     assert np.allclose(km.cpu().numpy()[same], kmo[same], rtol=1e-6)
     assert fa[3] == 0 and km[3] == 0
     assert np.mean(np.abs(ah[fa.cpu().numpy().astype(int)] - ah[fa_true.cpu().numpy().astype(int)]) <= 3.0) > 0.7      # it does estimate the flip angle
+
+
+def test_file_level_driver_on_disk_contract(pkg, tmp_path):
+    # NIfTI in, the driver's ten NIfTI volumes out (motor:167-182, 475-503)
+    motor = importlib.import_module(PKG + ".motor")
+    nifti = importlib.import_module(PKG + ".nifti")
+    g = np.load(os.path.join(GOLDEN, "golden_motor_x2_l2_bf.npz"))
+    aff = np.diag([1.5, 1.5, 3.0, 1.0])
+    nifti.save(nifti.NiftiImage(g["data"], aff), str(tmp_path / "data.nii.gz"))
+    nifti.save(nifti.NiftiImage(g["mask"].astype(np.uint8), aff), str(tmp_path / "mask.nii.gz"))
+    out = str(tmp_path) + "/recon_"
+    motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "None",
+                           "brute-force", "no", 40.0, 1)
+    for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
+        img = nifti.load(out + name + ".nii.gz")
+        assert np.allclose(img.affine, aff)
+        got = img.get_fdata()
+        assert got.shape == g[name].shape
+        if name == "FA":
+            assert np.array_equal(got, g[name])
+        elif name == "reg_param":
+            assert np.allclose(got, g[name], rtol=1e-4, atol=1e-12)
+        else:
+            assert np.max(np.abs(got - g[name])) / max(1.0, np.max(np.abs(g[name]))) < TOL, name
+    with pytest.raises(NotImplementedError):
+        motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "TV",
+                               "brute-force", "no", 40.0, 1)
