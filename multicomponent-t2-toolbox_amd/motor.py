@@ -151,3 +151,41 @@ def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR
     for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
         nifti.save(nifti.NiftiImage(res[name], img.affine), path_to_save_data + name + ".nii.gz")
     return res
+
+
+def recon_met2_rois(data, rois, fa_index, Dic_3D, T2s, Laplac, factor=1.01, myelin_T2=40.0, device=0):
+    """ROI-mode estimation (motor/motor_recon_met2_real_data_ROI.py:405-443): for every ROI label > 0 the mean signal and the
+    mean EPG kernel over its voxels (each voxel contributes the dictionary slice of its own flip angle), one X2 fit
+    (factor 1.01 there) per ROI, then the spectrum metrics.  data [..., nt], rois [...] integer labels, fa_index [...]
+    (indices into Dic_3D's FA axis), Dic_3D [nt, nT2, nFA] (reference layout).
+    Returns dict(labels, fsol [nROI, nT2] normalised to sum 1 like the reference, MWF, IEWF, FWF, T2_M, T2_IE, reg_opt, k_est)."""
+    data = np.asarray(data, dtype=np.float64)
+    nt = data.shape[-1]
+    d2 = data.reshape(-1, nt)
+    lab = np.asarray(rois).reshape(-1)
+    fa = np.asarray(fa_index).reshape(-1).astype(np.int64)
+    D3 = np.asarray(Dic_3D, dtype=np.float64)
+    nT2, nFA = D3.shape[1], D3.shape[2]
+    labels = np.array([v for v in np.unique(lab) if v > 0])
+    if labels.size == 0:
+        raise ValueError("no ROI label > 0")
+    sig = np.zeros((labels.size, nt))
+    W = np.zeros((labels.size, nFA))
+    for i, v in enumerate(labels):
+        sel = lab == v
+        sig[i] = d2[sel].sum(axis=0) / sel.sum()
+        W[i] = np.bincount(fa[sel], minlength=nFA) / sel.sum()
+    kernels = np.einsum("rf,etf->etr", W, D3)                      # mean kernel per ROI, [nt, nT2, nROI]
+    plan = Met2Plan(nt, nT2, labels.size, device=device, x2_factor=factor, myelin_T2=myelin_T2)
+    try:
+        plan.set_dictionary(np.ascontiguousarray(kernels)).set_t2_grid(T2s).set_penalty(np.asarray(Laplac, dtype=np.float64))
+        out = plan.fit("X2", torch.as_tensor(sig, device=plan.device),
+                       fa_index=torch.arange(labels.size, dtype=torch.float64, device=plan.device), want_lambda=True)
+        f = out["fsol"].cpu().numpy()
+        maps = out["maps"].cpu().numpy()
+        res = {"labels": labels, "fsol": f / maps[5][:, None], "reg_opt": out["lam"].cpu().numpy(), "k_est": out["reg"].cpu().numpy()}
+        for i, name in enumerate(MAP_NAMES[:5]):
+            res[name] = maps[i]
+        return res
+    finally:
+        plan.close()

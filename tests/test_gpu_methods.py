@@ -245,3 +245,28 @@ def test_file_level_driver_on_disk_contract(pkg, tmp_path):
     with pytest.raises(NotImplementedError):
         motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "TV",
                                "brute-force", "no", 40.0, 1)
+
+
+def test_roi_mode_x2(pkg):
+    # ROI-mode fits (motor_recon_met2_real_data_ROI.py:405-443): mean signal, mean kernel, X2 with factor 1.01
+    from oracle import oracle
+    motor = importlib.import_module(PKG + ".motor")
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(60); T1s = 1000.0 * np.ones(60); alphas = np.linspace(90.0, 180.0, 91)
+    Dic = importlib.import_module(PKG + ".epg").create_Dic_3D(60, T2s, T1s, 32, 10.0, alphas, 3000.0)
+    data, fa, _ = synth.make_voxels(600, nte=32, seed=51, fa_values=alphas, device="cuda")
+    data = data.cpu().numpy(); fa = fa.cpu().numpy()
+    rng = np.random.default_rng(2)
+    rois = rng.integers(0, 5, 600)                                  # label 0 = background
+    L = motor.create_Laplacian_matrix(60, 2)
+    res = motor.recon_met2_rois(data, rois, fa, Dic, T2s, L)
+    assert list(res["labels"]) == [1, 2, 3, 4]
+    for i, v in enumerate(res["labels"]):
+        sel = rois == v
+        tk = sum(Dic[:, :, int(k)] for k in fa[sel]) / sel.sum()
+        ts = data[sel].sum(axis=0) / sel.sum()
+        x, lam, kest = oracle.nnls_x2(tk, ts, L, 1.01)
+        xs = x / (x.sum() + 1e-16)
+        assert relmax(res["fsol"][i], xs) < TOL
+        assert abs(res["reg_opt"][i] - lam) < 1e-5 * max(lam, 1e-3) and abs(res["k_est"][i] - kest) < 1e-6
+        assert abs(res["MWF"][i] - xs[T2s <= 40.0].sum()) < TOL
