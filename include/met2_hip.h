@@ -161,6 +161,16 @@ int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const doub
                           int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
                           double *fa_index, double *xmin, void *stream);
 
+/* motor:305-333, the NESMA filter (denoise='NESMA').  DEVICE pointers: data [nx][ny][nz][n_te] (already
+ * multiplied by the mask and clipped at 0, motor:180-182 and :279), mask [nx][ny][nz] uint8 -- voxels with
+ * mask == 1 are filtered (motor:317), all others get zeros (NULL = filter every voxel); out [nx][ny][nz][n_te],
+ * must not alias data.  Each filtered voxel becomes the mean of the voxels in its half-open window
+ * [x-6, x+6) x [y-6, y+6) x [z-6, z+6) (clipped to the volume) whose relative L1 distance to it is < 2.5 %
+ * (nan when none qualifies, e.g. an all-zero signal, like np.mean of an empty selection).  n_te <= 128.
+ * Asynchronous on `stream`. */
+int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t n_te, const double *data,
+               const uint8_t *mask, double *out, void *stream);
+
 /* motor:443-472 alone (fsol already on the device). */
 int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps,
                  void *stream);

@@ -698,6 +698,172 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
 // minimize_scalar(method='Bounded'): xatol 1e-5, maxiter 500), snap to the fine FA grid.
 // One thread per voxel; the residuals come from fa_kernel on the coarse dictionary.
 // ------------------------------------------------------------------------------------------
+// NESMA filter (motor:305-333): every voxel with mask == 1 becomes the mean of the voxels of its
+// [x-6, x+6) x [y-6, y+6) x [z-6, z+6) window (clipped to the volume) whose relative L1 distance
+// 100 * sum|s_nb - s_c| / sum(s_c) is below 2.5 %.  One wave per output voxel, lane <-> echo; the
+// window is walked in batches of 8 neighbours: |s_nb - s_c| goes through the wave's LDS strip so
+// that lane group q (8 lanes) can sum neighbour q in the order of numpy's pairwise sum (8 running
+// sums, tree combine, tail in order), which keeps the 2.5 % test and the running mean bit-identical
+// to the reference's np.sum / np.mean.  The four waves of a workgroup take consecutive z, so their
+// windows overlap by 11/12 and the re-reads hit L1/L2.
+// ------------------------------------------------------------------------------------------
+#define MET2_NESMA_HW 6
+#define MET2_NESMA_MAX_NT 128
+struct NesmaArgs {
+    int nx, ny, nz, nt;
+    const double *data;       // [nx][ny][nz][nt]
+    const uint8_t *mask;      // [nx][ny][nz], filtered where == 1 (NULL = everywhere)
+    double *out;              // [nx][ny][nz][nt]
+    int64_t nvox;
+    int srow;                 // LDS row stride in doubles: >= nt, = 8 mod 32
+};
+
+// numpy pairwise sum of S[q][0..nt) for the lane's group q = lane / 8 (nt <= 128): valid on every lane of the group
+__device__ __forceinline__ double np_rowsum_group(const double *Sq, int nt, int j)
+{
+    double r;
+    if (nt < 8) {
+        r = 0.0;
+        for (int i = 0; i < nt; ++i) r += Sq[i];
+        return r;
+    }
+    const int n8 = nt - (nt & 7);
+    r = Sq[j];
+    for (int i = 8; i < n8; i += 8) r += Sq[i + j];
+    r = r + dpp_mov<0xB1>(r);       // r0+r1 | r2+r3 | ...
+    r = r + dpp_mov<0x4E>(r);       // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+    r = r + dpp_mov<0x141>(r);      // both halves of the group
+    for (int i = n8; i < nt; ++i) r += Sq[i];
+    return r;
+}
+
+// RE < 2.5 with RE = fl(fl(100 S) / sumc), decided without the division whenever 100 S is clear of 2.5 sumc by
+// more than the rounding of both sides (the exact quotient is only formed for the voxels inside that band)
+struct NesmaTest {
+    double sumc, lo, hi;
+    bool fast;
+    __device__ __forceinline__ void init(double sc)
+    {
+        sumc = sc; fast = sc > 0.0 && sc < 1e300;
+        lo = 2.5 * sc * (1.0 - 1e-15); hi = 2.5 * sc * (1.0 + 1e-15);
+    }
+    __device__ __forceinline__ u64 similar(double S) const
+    {
+        const double t = 100.0 * S;
+        const bool yes = t < lo, no = !(t <= hi);
+        if (fast && ballot(!yes && !no) == 0ull) return ballot(yes);
+        return ballot(t / sumc < 2.5);
+    }
+};
+
+// the value the lane 32 above holds (v_permlane32_swap: upper half of one operand <-> lower half of the other)
+__device__ __forceinline__ double from_upper_half(double v)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// One batch = the z-run of one (x, y) of the window: up to 12 neighbours that are contiguous in memory, so the
+// window walk is two nested loops with a pointer bump and the batch geometry (run length L) is fixed per voxel.
+// PACK = 1: lane <-> echo (NE echoes per lane), one neighbour per load.  PACK = 2 (nt <= 32): the two halves of the
+// wave load two consecutive neighbours at once; the running sum lives in the lower half and takes the odd neighbours
+// through v_permlane32_swap so that the additions keep the reference's order.  LDS rows are padded to a stride of
+// 8 mod 32 doubles, which spreads the 8 lane groups of a row-sum read over all banks.
+template <int NE, int PACK>
+__global__ __launch_bounds__(256) void nesma_kernel(NesmaArgs A)
+{
+    extern __shared__ double nesma_lds[];
+    constexpr int STEPS = 2 * MET2_NESMA_HW / PACK;
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6), nt = A.nt, SR = A.srow;
+    double *S = nesma_lds + (size_t)w * 2 * MET2_NESMA_HW * SR;
+    // workgroups are dealt round-robin to the 8 XCDs: give XCD i the i-th contiguous eighth of the volume so that
+    // the windows its CUs walk at the same time overlap in its own L2
+    const unsigned nb = gridDim.x, per = (nb + 7u) / 8u;
+    const unsigned bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const int64_t v = (int64_t)bid * 4 + w;
+    if (bid >= nb || v >= A.nvox) return;                      // wave-uniform
+    const int h = PACK == 2 ? lane >> 5 : 0;
+    const int e0 = PACK == 2 ? (lane & 31) : lane, e1 = lane + 64;
+    const bool has0 = e0 < nt, has1 = NE > 1 && e1 < nt;
+    const bool writer = h == 0;
+    double *orow = A.out + v * nt;
+    if (A.mask && A.mask[v] != 1) {
+        if (has0 && writer) orow[e0] = 0.0;
+        if (has1) orow[e1] = 0.0;
+        return;
+    }
+    const int z = (int)(v % A.nz), y = (int)((v / A.nz) % A.ny), x = (int)(v / ((int64_t)A.nz * A.ny));
+    const int x0 = max(x - MET2_NESMA_HW, 0), x1 = min(x + MET2_NESMA_HW, A.nx);
+    const int y0 = max(y - MET2_NESMA_HW, 0), y1 = min(y + MET2_NESMA_HW, A.ny);
+    const int z0 = max(z - MET2_NESMA_HW, 0), z1 = min(z + MET2_NESMA_HW, A.nz);
+    const int L = z1 - z0;                                     // 1..12 neighbours per batch
+    const int q = lane >> 3, j = lane & 7;
+    const double *crow = A.data + v * nt;
+    const double c0 = has0 ? crow[e0] : 0.0, c1 = has1 ? crow[e1] : 0.0;
+    if (has0 && writer) S[e0] = c0;
+    if (has1) S[e1] = c1;
+    __builtin_amdgcn_wave_barrier();
+    NesmaTest T;
+    T.init(bcast(np_rowsum_group(S, nt, j), 0));
+    __builtin_amdgcn_wave_barrier();
+    const double *S0 = S + min(q, L - 1) * SR, *S1 = S + min(8 + (q & 3), L - 1) * SR;
+    const int64_t ystride = (int64_t)A.nz * nt, xstride = ystride * A.ny;
+    unsigned off0[STEPS], off1[STEPS];                         // the lane's element of each row of a run
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        const int r = min(PACK * t + h, L - 1);
+        off0[t] = (unsigned)(r * nt + min(e0, nt - 1));
+        off1[t] = (unsigned)(r * nt + min(e1, nt - 1));
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    int cnt = 0;
+    for (int i = x0; i < x1; ++i) {
+        const double *strip = A.data + i * xstride + y0 * ystride + (int64_t)z0 * nt;
+        for (int jj = y0; jj < y1; ++jj, strip += ystride) {
+            // all loads of the run first (rows past the run re-read its last row; they are never summed), then the
+            // |difference| rows into LDS
+            double nb0[STEPS], nb1[STEPS];
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t) {
+                nb0[t] = strip[off0[t]];
+                nb1[t] = NE > 1 ? strip[off1[t]] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t) {
+                const int r = PACK * t + h;
+                if (has0) S[r * SR + e0] = fabs(nb0[t] - c0);
+                if (NE > 1 && has1) S[r * SR + e1] = fabs(nb1[t] - c1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const u64 ok0 = T.similar(np_rowsum_group(S0, nt, j));           // 8 identical bits per lane group
+            const u64 ok1 = L > 8 ? T.similar(np_rowsum_group(S1, nt, j)) : 0ull;
+            __builtin_amdgcn_wave_barrier();
+            unsigned vm = 0;                                                 // bit r: neighbour r of the run is similar
+#pragma unroll
+            for (int r = 0; r < 8; ++r) vm |= (unsigned)((ok0 >> (8 * r)) & 1ull) << r;
+#pragma unroll
+            for (int r = 8; r < 2 * MET2_NESMA_HW; ++r) vm |= (unsigned)((ok1 >> (8 * (r - 8))) & 1ull) << r;
+            vm &= (1u << L) - 1u;
+            cnt += __builtin_popcount(vm);
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t) {
+                if (PACK == 1) {
+                    if ((vm >> t) & 1u) { acc0 += nb0[t]; if (NE > 1) acc1 += nb1[t]; }
+                } else {
+                    if ((vm >> (2 * t)) & 1u) acc0 += nb0[t];
+                    if ((vm >> (2 * t + 1)) & 1u) acc0 += from_upper_half(nb0[t]);
+                }
+            }
+        }
+    }
+    const double dc = (double)cnt;                             // empty set -> 0/0 = nan, as np.mean of nothing
+    if (has0 && writer) orow[e0] = acc0 / dc;
+    if (has1) orow[e1] = acc1 / dc;
+}
+
+// ------------------------------------------------------------------------------------------
 #define MET2_MAX_LR 32
 struct SplineArgs {
     int nlr, nhr, nte;
@@ -994,6 +1160,30 @@ static void spline_weights_host(int n, const double *x, std::vector<double> &W)
             for (int q = c + 1; q < n; ++q) t -= A[(size_t)c * n + q] * W[(size_t)q * n + j];
             W[(size_t)c * n + j] = t / A[(size_t)c * n + c];
         }
+}
+
+extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t nt, const double *data,
+                          const uint8_t *mask, double *out, void *stream)
+{
+    if (nx < 0 || ny < 0 || nz < 0 || nt < 1) return fail(MET2_E_INVALID, "bad shape");
+    if (nt > MET2_NESMA_MAX_NT) return fail(MET2_E_UNSUPPORTED, "NESMA supports at most 128 echoes");
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    if (nvox == 0) return MET2_OK;
+    if (!data || !out) return fail(MET2_E_INVALID, "NULL argument");
+    if (data == out) return fail(MET2_E_INVALID, "NESMA cannot run in place");
+    if ((nvox + 3) / 4 > 0x7fffffffLL) return fail(MET2_E_UNSUPPORTED, "volume too large for one launch");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    NesmaArgs A;
+    A.nx = nx; A.ny = ny; A.nz = nz; A.nt = nt; A.data = data; A.mask = mask; A.out = out; A.nvox = nvox;
+    const dim3 grid((unsigned)((((nvox + 3) / 4 + 7) / 8) * 8)), block(256);      // a multiple of 8 for the XCD remap
+    A.srow = ((nt + 23) / 32) * 32 + 8;
+    const size_t lds = sizeof(double) * 4 * 2 * MET2_NESMA_HW * (size_t)A.srow;
+    if (nt <= 32)      hipLaunchKernelGGL((nesma_kernel<1, 2>), grid, block, lds, s, A);
+    else if (nt <= 64) hipLaunchKernelGGL((nesma_kernel<1, 1>), grid, block, lds, s, A);
+    else               hipLaunchKernelGGL((nesma_kernel<2, 1>), grid, block, lds, s, A);
+    HIPCHK(hipGetLastError());
+    return MET2_OK;
 }
 
 extern "C" int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,

@@ -1,12 +1,13 @@
-"""Drop-ins for the voxel loop of motor/motor_recon_met2_real_data.py: create_Laplacian_matrix,
-fitting_slice_T2, and recon_met2_arrays -- the driver's steps 2-4 on in-memory arrays (NIfTI I/O,
-denoising, plots and the mean-spectrum diagnostics are out of scope)."""
+"""Drop-ins for motor/motor_recon_met2_real_data.py: create_Laplacian_matrix, fitting_slice_T2, the NESMA filter,
+recon_met2_arrays (the driver's steps 1-4 on in-memory arrays), motor_recon_met2 (the same with the on-disk
+contract) and the ROI mode.  TV denoising (scikit-image), plots and the mean-spectrum PNG are not reproduced."""
 import math
 
 import numpy as np
 import torch
 
 from ._cache import plan_for
+from ._lib import check, lib
 from .plan import MAP_NAMES, Met2Plan
 
 
@@ -63,20 +64,51 @@ def fitting_slice_T2(mask_1d, data_1d, FA_index_1d, nx, Dic_3D, lambda_reg, T2di
     return out["fsol"].cpu().numpy(), out["sig"].cpu().numpy(), out["reg"].cpu().numpy()
 
 
+def nesma_filter(data, mask, device=0):
+    """The NESMA filter of the driver (motor:305-333) on the device: `data` [nx,ny,nz,nt] as the driver holds it at
+    that point (multiplied by the mask, negatives clipped), `mask` [nx,ny,nz]; voxels with mask == 1 become the
+    mean of the similar voxels (relative L1 distance < 2.5 %) of their 12^3 window, all others zero.  Accepts numpy
+    arrays (returns numpy) or CUDA tensors (returns a tensor on the same device)."""
+    as_numpy = not torch.is_tensor(data)
+    dev = torch.device("cuda", device) if as_numpy else data.device
+    dd = torch.as_tensor(data, dtype=torch.float64, device=dev).contiguous()
+    if dd.dim() != 4 or tuple(np.shape(mask)) != tuple(dd.shape[:3]):
+        raise ValueError("data must be [nx,ny,nz,nt] and mask [nx,ny,nz]")
+    mk = (torch.as_tensor(mask, device=dev) == 1).to(torch.uint8).contiguous()
+    out = torch.empty_like(dd)
+    nx, ny, nz, nt = dd.shape
+    with torch.cuda.device(dev):
+        check(lib().met2_nesma(dev.index or 0, nx, ny, nz, nt, dd.data_ptr(), mk.data_ptr(), out.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream))
+    return out.cpu().numpy() if as_numpy else out
+
+
 def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
-                      fa_index=None, device=0, plan=None):
-    """Steps 2-4 of motor_recon_met2 (motor:336-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
+                      fa_index=None, device=0, plan=None, denoise="None", prepared=False):
+    """Steps 1-4 of motor_recon_met2 (motor:293-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
     [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
-    negative values clipped to 0 (motor:279), Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms,
-    T1 = 1000 ms, 91 flip angles for brute force.  Returns a dict with the driver's ten outputs."""
+    negative values clipped to 0 (motor:279), optional NESMA filter (motor:305-333, needs a 3-D volume),
+    Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms, T1 = 1000 ms, 91 flip angles for brute force.
+    `prepared=True` says the caller already did that preparation (mask multiply, clip, denoise).
+    Returns a dict with the driver's ten outputs."""
     if FA_method not in ("brute-force", "spline"):
         raise ValueError("FA_method must be 'spline' or 'brute-force'")
+    if denoise not in ("None", None, "none", "NESMA"):
+        raise NotImplementedError("denoise=%r is not built: TV (motor:293-304) is scikit-image's estimate_sigma + "
+                                  "denoise_tv_chambolle, a third-party dependency outside the path" % (denoise,))
     data = np.asarray(data, dtype=np.float64)
     vol_shape = data.shape[:-1]
     nt = data.shape[-1]
     mask = np.asarray(mask).reshape(vol_shape)
-    d2 = (data * (mask[..., None] != 0)).reshape(-1, nt)
-    d2 = np.where(d2 < 0.0, 0.0, d2)
+    d2 = data
+    if not prepared:
+        d2 = data * mask[..., None]                   # the mask VALUE multiplies (motor:180-182)
+        d2 = np.where(d2 < 0.0, 0.0, d2)
+        if denoise == "NESMA":
+            if len(vol_shape) != 3:
+                raise ValueError("NESMA needs data [nx,ny,nz,nt]")
+            d2 = nesma_filter(d2, mask, device=device)
+    d2 = d2.reshape(-1, nt)
     m1 = (mask.reshape(-1) > 0)
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
@@ -125,26 +157,29 @@ def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR
     """Drop-in for motor_recon_met2 (motor:165-506) with the reference's on-disk contract: NIfTI in
     (data [nx,ny,nz,nt], mask [nx,ny,nz]), ten NIfTI volumes out (MWF, IEWF, FWF, T2_M, T2_IE, TWC, FA, fsol_4D,
     Est_Signal, reg_param .nii.gz at path_to_save_data, motor:475-503).  `num_cores` is accepted and ignored (one
-    process drives the GPU).  Not reproduced: TV / NESMA denoising (motor:293-334; denoise must be 'None') and the
-    mean-spectrum PNG of motor:377-424."""
+    process drives the GPU).  denoise: 'None' or 'NESMA' (motor:305-333).  Not reproduced: TV denoising (motor:293-304,
+    scikit-image) and the mean-spectrum PNG of motor:377-424."""
     from . import nifti
-    if denoise not in ("None", None, "none"):
-        raise NotImplementedError("denoise=%r is not built (motor:293-334 is outside the hot path)" % (denoise,))
+    if denoise not in ("None", None, "none", "NESMA"):
+        raise NotImplementedError("denoise=%r is not built (TV, motor:293-304, is scikit-image code outside the path)" % (denoise,))
     img = nifti.load(path_to_data)
     data = img.get_fdata().astype(np.float64, copy=False)
     mask = nifti.load(path_to_mask).get_fdata().astype(np.int64)
     if data.ndim != 4 or mask.shape != data.shape[:3]:
         raise ValueError("data must be 4-D and mask must match its first three dimensions")
     fa_index = None
+    dm = data * mask[..., None]                       # motor:180-182
+    dm[dm < 0.0] = 0.0                                # motor:279
+    if denoise == "NESMA":
+        dm = nesma_filter(dm, mask, device=device)    # motor:305-333
     if FA_smooth == "yes":
-        # motor:337-343: the flip angle is estimated on Gaussian-smoothed data (sigma 2 voxels), the spectra on the raw data
+        # motor:337-343: the flip angle is estimated on Gaussian-smoothed data (sigma 2 voxels), the spectra on the unsmoothed data
         import scipy.ndimage as filt
-        dm = data * (mask[..., None] != 0)
-        dm[dm < 0.0] = 0.0
         sm = np.stack([filt.gaussian_filter(dm[..., c], 2.0, 0) for c in range(dm.shape[-1])], axis=-1)
-        pre = recon_met2_arrays(sm, mask, TE_array, TR, "NNLS", reg_matrix, FA_method, myelin_T2, device=device)
+        pre = recon_met2_arrays(sm, mask, TE_array, TR, "NNLS", reg_matrix, FA_method, myelin_T2, device=device, prepared=True)
         fa_index = pre["FA_index"]
-    res = recon_met2_arrays(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index=fa_index, device=device)
+    res = recon_met2_arrays(dm, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index=fa_index, device=device,
+                            prepared=True)
     if fa_index is not None:
         n_alpha = 91 * 3 if FA_method == "spline" else 91
         res["FA"] = np.where(mask > 0, np.linspace(90.0, 180.0, n_alpha)[np.asarray(fa_index).astype(int)], 0.0)

@@ -24,6 +24,7 @@
  *   motor/motor_recon_met2_real_data.py:113-162 -> met2o_fit_batch
  *   motor/motor_recon_met2_real_data.py:443-472 -> met2o_metrics
  *   flip_angle_algorithms/fa_estimation.py:74-90 -> met2o_fa_bruteforce
+ *   motor/motor_recon_met2_real_data.py:305-333 -> met2o_nesma
  *   flip_angle_algorithms/fa_estimation.py:35-70 -> met2o_fa_spline (scipy interp1d(kind='cubic') =
  *        not-a-knot cubic spline; scipy minimize_scalar(method='Bounded') = the same bounded Brent)
  */
@@ -1007,6 +1008,62 @@ MET2O_API void met2o_fa_spline(int nte, int nt2, int nlr, const double *Dlr, con
             idx[v] = (double)best; km[v] = s; if (xmin) xmin[v] = xs;
         }
         free(f); free(res); free(sl); free(work); ws_free(W);
+    }
+}
+
+/* ------------------------------------------------------------------ NESMA filter (motor:305-333) */
+/* numpy's pairwise summation of a contiguous vector (np.sum(..., axis=1) at motor:325): 8 running sums,
+ * combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), remainder added in order; blocks of at most 128. */
+static double np_pairwise_sum(const double *a, int n)
+{
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* data [nx][ny][nz][nt] (already multiplied by the mask and clipped, motor:180-182, 279), mask as float64;
+ * voxels with mask == 1 get the mean of the window voxels whose relative L1 distance is below 2.5 % */
+MET2O_API void met2o_nesma(int nx, int ny, int nz, int nt, const double *data, const double *mask, double *out, int nthreads)
+{
+    const int hw = 6;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    memset(out, 0, sizeof(double) * (size_t)nx * ny * nz * nt);
+#pragma omp parallel
+    {
+        double *diff = (double *)malloc(sizeof(double) * nt), *acc = (double *)malloc(sizeof(double) * nt);
+#pragma omp for schedule(dynamic, 8) collapse(2)
+        for (int x = 0; x < nx; ++x)
+            for (int y = 0; y < ny; ++y)
+                for (int z = 0; z < nz; ++z) {
+                    const size_t v = ((size_t)x * ny + y) * nz + z;
+                    if (mask[v] != 1.0) continue;
+                    const double *c = data + v * nt;
+                    const double sumc = np_pairwise_sum(c, nt);
+                    const int x0 = x - hw < 0 ? 0 : x - hw, x1 = x + hw > nx ? nx : x + hw;
+                    const int y0 = y - hw < 0 ? 0 : y - hw, y1 = y + hw > ny ? ny : y + hw;
+                    const int z0 = z - hw < 0 ? 0 : z - hw, z1 = z + hw > nz ? nz : z + hw;
+                    for (int e = 0; e < nt; ++e) acc[e] = 0.0;
+                    int cnt = 0;
+                    for (int i = x0; i < x1; ++i) for (int j = y0; j < y1; ++j) for (int k = z0; k < z1; ++k) {
+                        const double *nb = data + (((size_t)i * ny + j) * nz + k) * nt;
+                        for (int e = 0; e < nt; ++e) diff[e] = fabs(nb[e] - c[e]);
+                        const double RE = 100.0 * np_pairwise_sum(diff, nt) / sumc;
+                        if (RE < 2.5) { for (int e = 0; e < nt; ++e) acc[e] += nb[e]; cnt++; }
+                    }
+                    for (int e = 0; e < nt; ++e) out[v * nt + e] = acc[e] / (double)cnt;      /* mean of an empty set: nan */
+                }
+        free(diff); free(acc);
     }
 }
 

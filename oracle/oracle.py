@@ -219,5 +219,14 @@ def spline_weights(x):
     return W
 
 
+def nesma(data, mask, nthreads=1):
+    """motor:305-333 on data [nx,ny,nz,nt] (already masked and clipped) -> filtered volume"""
+    data = _d(data); mask = _d(mask)
+    nx, ny, nz, nt = data.shape
+    out = np.zeros_like(data)
+    lib().met2o_nesma(nx, ny, nz, nt, _p(data), _p(mask), _p(out), int(nthreads))
+    return out
+
+
 def max_threads():
     return lib().met2o_max_threads()

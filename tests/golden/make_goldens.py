@@ -367,9 +367,57 @@ def gen_motor(tag, reg_method, reg_matrix, fa_method, seed):
     print("wrote golden_motor_%s.npz" % tag)
 
 
+def gen_nesma(seed):
+    """The NESMA filter of motor:305-333 is inline in the driver.  The driver is run with denoise='NESMA' on a small
+    volume and the rows handed to the FA step (motor:354-357: `data_smooth = data.copy()` after the filter) are
+    recorded, which gives the filtered volume itself next to the end-to-end outputs."""
+    from epg.epg import epg_signal
+    import motor.motor_recon_met2_real_data as motor
+    import matplotlib
+    matplotlib.rcParams["text.usetex"] = False
+    rng = np.random.default_rng(seed)
+    nx, ny, nz, nte = 9, 8, 5, 32
+    # piecewise-constant tissue classes so that the similarity test (RE < 2.5 %) has neighbours to accept
+    cls, _ = synth_voxels(rng, 3, nte, epg_signal, fa_deg=150.0, snr_lo=np.inf, snr_hi=np.inf)
+    lab = rng.integers(0, 3, (nx, ny, nz))
+    data = cls[lab] * (1.0 + 0.004 * rng.standard_normal((nx, ny, nz, nte)))
+    mask = np.ones((nx, ny, nz)); mask[0, 0, :] = 0; mask[5, 5, 2] = 0
+    mask[8, 7, 4] = 2                     # a mask value other than 1 is skipped by the filter (motor:317)
+    _NIB_FILES["nes_data"] = data
+    _NIB_FILES["nes_mask"] = mask
+    rows = {}
+    orig = motor.fitting_slice_FA_brute_force
+    state = {"z": -1, "y": 0}
+
+    def spy(mask_1d, data_1d, nx_, Dic_3D, alpha_values):
+        if state["y"] == 0:
+            state["z"] += 1
+        rows[(state["y"], state["z"])] = np.array(data_1d)
+        state["y"] = (state["y"] + 1) % ny
+        return orig(mask_1d, data_1d, nx_, Dic_3D, alpha_values)
+
+    motor.fitting_slice_FA_brute_force = spy
+    TE = 10.0 * np.arange(1, nte + 1)
+    os.makedirs("/tmp/met2_golden_png", exist_ok=True)
+    prefix = "/tmp/met2_golden_png/nesma_"
+    try:
+        with np.errstate(all="ignore"):
+            motor.motor_recon_met2(TE, "nes_data", "nes_mask", prefix, 3000.0, "X2", "L2", "NESMA", "brute-force", "no", 40.0, 1)
+    finally:
+        motor.fitting_slice_FA_brute_force = orig
+    den = np.zeros_like(data)
+    for (y, z), r in rows.items():
+        den[:, y, z, :] = r
+    out = {"data": data, "mask": mask, "TE": TE, "denoised": den}
+    for name in ("MWF", "FA", "fsol_4D", "reg_param"):
+        out[name] = _NIB_FILES[prefix + name + ".nii.gz"]
+    np.savez_compressed(os.path.join(HERE, "golden_nesma.npz"), **out)
+    print("wrote golden_nesma.npz")
+
+
 def main():
     install_shims()
-    which = sys.argv[1:] or ["S1", "S2", "motor"]
+    which = sys.argv[1:] or ["S1", "S2", "motor", "nesma"]
     if "S1" in which:
         gen_shape("S1", 32, 60, nvox=32, nvox_slow=32, seed=20260101, with_fa_full=True)
     if "S2" in which:
@@ -377,6 +425,8 @@ def main():
     if "motor" in which:
         gen_motor("x2_l2_bf", "X2", "L2", "brute-force", 20260111)
         gen_motor("lcurve_l1_spline", "L_curve", "L1", "spline", 20260112)
+    if "nesma" in which:
+        gen_nesma(20260113)
 
 
 if __name__ == "__main__":

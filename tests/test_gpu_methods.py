@@ -247,6 +247,65 @@ def test_file_level_driver_on_disk_contract(pkg, tmp_path):
                                "brute-force", "no", 40.0, 1)
 
 
+def test_nesma_filter_and_driver_golden(pkg, tmp_path):
+    # the NESMA filter (motor:305-333) -- bit-exact against the rows the reference's driver
+    # produced, then the whole denoise='NESMA' run (brute-force FA, X2/L2, metrics) against the reference's maps
+    motor = importlib.import_module(PKG + ".motor")
+    nifti = importlib.import_module(PKG + ".nifti")
+    g = np.load(os.path.join(GOLDEN, "golden_nesma.npz"))
+    dm = g["data"] * g["mask"][..., None]
+    dm = np.where(dm < 0, 0.0, dm)
+    den = motor.nesma_filter(dm, g["mask"])
+    assert np.array_equal(den, g["denoised"], equal_nan=True)
+    res = motor.recon_met2_arrays(g["data"], g["mask"], g["TE"], 3000.0, "X2", "L2", "brute-force", 40.0, denoise="NESMA")
+    assert np.array_equal(res["FA"], g["FA"])
+    assert relmax(res["fsol_4D"], g["fsol_4D"]) < TOL
+    assert np.allclose(res["reg_param"], g["reg_param"], rtol=1e-4, atol=1e-12)
+    assert np.max(np.abs(res["MWF"] - g["MWF"])) < TOL
+    # the on-disk driver with the same switch
+    aff = np.eye(4)
+    nifti.save(nifti.NiftiImage(g["data"], aff), str(tmp_path / "data.nii.gz"))
+    nifti.save(nifti.NiftiImage(g["mask"].astype(np.uint8), aff), str(tmp_path / "mask.nii.gz"))
+    out = str(tmp_path) + "/nesma_"
+    motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "NESMA",
+                           "brute-force", "no", 40.0, 1)
+    assert np.max(np.abs(nifti.load(out + "MWF.nii.gz").get_fdata() - g["MWF"])) < TOL
+    assert np.array_equal(nifti.load(out + "FA.nii.gz").get_fdata(), g["FA"])
+
+
+@pytest.mark.parametrize("shape", [(20, 17, 15, 32), (7, 30, 9, 48), (14, 5, 13, 100), (3, 2, 2, 5), (1, 1, 1, 32)])
+def test_nesma_vs_oracle(pkg, shape):
+    # ragged volumes, echo counts on both kernel variants (<= 64 and <= 128), partial masks, an all-zero voxel
+    import torch
+    from oracle import oracle
+    motor = importlib.import_module(PKG + ".motor")
+    rng = np.random.default_rng(sum(shape))
+    nx, ny, nz, nt = shape
+    base = rng.uniform(0.5, 2.0, size=(2, nt)) * np.exp(-np.arange(nt) / 12.0)
+    lab = rng.integers(0, 2, size=(nx, ny, nz))
+    d = base[lab] * (1.0 + 0.01 * rng.standard_normal((nx, ny, nz, nt)))
+    m = (rng.uniform(size=(nx, ny, nz)) > 0.2).astype(np.int64)
+    if nx > 2:
+        m[2, 0, 0] = 1; d[2, 0, 0] = 0.0                         # no similar voxel -> nan row
+        m[1, 1, 1] = 3                                           # only mask == 1 is filtered
+    d = d * m[..., None]
+    want = oracle.nesma(d, m.astype(float), nthreads=8)
+    got = motor.nesma_filter(torch.as_tensor(d, device="cuda"), m)
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+    if nx > 2:
+        assert np.all(np.isnan(want[2, 0, 0])) and np.all(want[1, 1, 1] == 0)
+
+
+def test_nesma_errors(pkg):
+    import torch
+    motor = importlib.import_module(PKG + ".motor")
+    with pytest.raises(ValueError):
+        motor.nesma_filter(np.zeros((4, 4, 4)), np.ones((4, 4, 4)))
+    with pytest.raises(pkg.Met2Error):
+        motor.nesma_filter(np.zeros((2, 2, 2, 129)), np.ones((2, 2, 2)))
+    assert motor.nesma_filter(np.zeros((0, 3, 3, 8)), np.ones((0, 3, 3))).shape == (0, 3, 3, 8)
+
+
 def test_roi_mode_x2(pkg):
     # ROI-mode fits (motor_recon_met2_real_data_ROI.py:405-443): mean signal, mean kernel, X2 with factor 1.01
     from oracle import oracle

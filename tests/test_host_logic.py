@@ -65,7 +65,7 @@ def test_oracle_pipeline_vs_driver_golden(oracle, tag, meth, pen):
     data = g["data"]; mask = g["mask"]
     shp = mask.shape
     nt = data.shape[-1]
-    d2 = (data * (mask[..., None] != 0)).reshape(-1, nt)
+    d2 = (data * mask[..., None]).reshape(-1, nt)
     d2 = np.where(d2 < 0, 0.0, d2)
     m1 = (mask.reshape(-1) > 0).astype(float)
     T2s = np.logspace(1, np.log10(2000.0), 60); T1s = 1000.0 * np.ones(60); alphas = np.linspace(90.0, 180.0, 91)
@@ -88,7 +88,7 @@ def test_oracle_spline_pipeline_vs_driver_golden(oracle):
     g = np.load(os.path.join(GOLDEN, "golden_motor_lcurve_l1_spline.npz"))
     data = g["data"]; mask = g["mask"]
     shp = mask.shape; nt = data.shape[-1]
-    d2 = (data * (mask[..., None] != 0)).reshape(-1, nt)
+    d2 = (data * mask[..., None]).reshape(-1, nt)
     d2 = np.where(d2 < 0, 0.0, d2)
     m1 = (mask.reshape(-1) > 0).astype(float)
     T2s = np.logspace(1, np.log10(2000.0), 60); T1s = 1000.0 * np.ones(60)
@@ -105,6 +105,48 @@ def test_oracle_spline_pipeline_vs_driver_golden(oracle):
     maps = oracle.metrics(fs, T2s, m1)
     for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
         assert np.allclose(maps[name].reshape(shp), g[name], rtol=1e-8, atol=1e-12), name
+
+
+def test_oracle_nesma_vs_driver_golden(oracle):
+    # the NESMA filter (motor:305-333).  The golden holds the rows the reference's driver handed
+    # to its FA step after filtering, and its end-to-end maps (denoise='NESMA', X2/L2, brute force; mask has a 2)
+    g = np.load(os.path.join(GOLDEN, "golden_nesma.npz"))
+    data = g["data"]; mask = g["mask"]
+    shp = mask.shape; nt = data.shape[-1]
+    dm = data * mask[..., None]
+    dm = np.where(dm < 0, 0.0, dm)
+    den = oracle.nesma(dm, mask, nthreads=4)
+    assert np.array_equal(den, g["denoised"], equal_nan=True)
+    assert np.all(den[mask != 1] == 0) and np.count_nonzero(np.abs(den - dm).sum(axis=-1)) > 300
+    d2 = den.reshape(-1, nt); m1 = (mask.reshape(-1) > 0).astype(float)
+    T2s = np.logspace(1, np.log10(2000.0), 60); T1s = 1000.0 * np.ones(60); alphas = np.linspace(90.0, 180.0, 91)
+    D = oracle.dictionary_fa_major(60, T2s, T1s, nt, 10.0, alphas, 3000.0)
+    idx, km, sse, f = oracle.fa_bruteforce(D, d2, m1, nthreads=4)
+    fitted = (m1 > 0) & (d2.sum(axis=1) > 0)
+    assert np.array_equal(np.where(fitted, alphas[idx.astype(int)], 0.0).reshape(shp), g["FA"])
+    fs, sg, rg, st = oracle.fit_batch("X2", D, oracle.penalty(60, "L2", T2s), d2, idx, m1, nthreads=4)
+    assert relmax(fs.reshape(shp + (60,)), g["fsol_4D"]) < 1e-8
+    assert np.allclose(rg.reshape(shp), g["reg_param"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(oracle.metrics(fs, T2s, m1)["MWF"].reshape(shp), g["MWF"], rtol=1e-8, atol=1e-12)
+
+
+def test_oracle_nesma_edge_cases(oracle):
+    # an all-zero signal inside the mask has no similar voxel (0/0 in the relative distance): mean of nothing = nan,
+    # as numpy gives the reference; a 1-voxel volume is its own neighbour only for x-6 <= x < x+6
+    rng = np.random.default_rng(5)
+    d = rng.uniform(1.0, 2.0, size=(3, 2, 2, 11)); m = np.ones((3, 2, 2)); d[1, 1, 1] = 0.0
+    out = oracle.nesma(d, m)
+    assert np.all(np.isnan(out[1, 1, 1])) and np.isfinite(np.delete(out.reshape(-1, 11), 7, axis=0)).all()
+    one = oracle.nesma(d[:1, :1, :1], m[:1, :1, :1])
+    assert np.array_equal(one, d[:1, :1, :1])
+    # numpy's own evaluation of the same expression (pairwise np.sum over 11 and over 130 echoes)
+    for nt in (5, 11, 40, 130):
+        d = rng.uniform(1.0, 1.05, size=(4, 3, 2, nt)); m = np.ones((4, 3, 2))
+        ref = np.zeros_like(d); flat = d.reshape(-1, nt)
+        for i in range(flat.shape[0]):
+            RE = 100 * np.sum(np.abs(flat - flat[i]), axis=1) / np.sum(flat[i])
+            ref.reshape(-1, nt)[i] = np.mean(flat[RE < 2.5, :], axis=0)
+        assert np.array_equal(oracle.nesma(d, m), ref), nt
 
 
 def test_spline_weights_match_scipy(oracle):
