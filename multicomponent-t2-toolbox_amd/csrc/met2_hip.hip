@@ -771,12 +771,14 @@ __device__ __forceinline__ double from_upper_half(double v)
 // wave load two consecutive neighbours at once; the running sum lives in the lower half and takes the odd neighbours
 // through v_permlane32_swap so that the additions keep the reference's order.  LDS rows are padded to a stride of
 // 8 mod 32 doubles, which spreads the 8 lane groups of a row-sum read over all banks.
-template <int NE, int PACK>
+// NT > 0 fixes the echo count at compile time (row sums fully unrolled); NT = 0 reads it from the arguments.
+template <int NE, int PACK, int NT>
 __global__ __launch_bounds__(256) void nesma_kernel(NesmaArgs A)
 {
     extern __shared__ double nesma_lds[];
     constexpr int STEPS = 2 * MET2_NESMA_HW / PACK;
-    const int lane = lane_id(), w = (int)(threadIdx.x >> 6), nt = A.nt, SR = A.srow;
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const int nt = NT > 0 ? NT : A.nt, SR = NT > 0 ? ((NT + 23) / 32) * 32 + 8 : A.srow;
     double *S = nesma_lds + (size_t)w * 2 * MET2_NESMA_HW * SR;
     // workgroups are dealt round-robin to the 8 XCDs: give XCD i the i-th contiguous eighth of the volume so that
     // the windows its CUs walk at the same time overlap in its own L2
@@ -817,6 +819,8 @@ __global__ __launch_bounds__(256) void nesma_kernel(NesmaArgs A)
         off0[t] = (unsigned)(r * nt + min(e0, nt - 1));
         off1[t] = (unsigned)(r * nt + min(e1, nt - 1));
     }
+    u64 live0 = 0, live1 = 0;                                  // bit 8 r set for the rows a run has
+    for (int r = 0; r < L; ++r) { if (r < 8) live0 |= 1ull << (8 * r); else live1 |= 1ull << (8 * (r - 8)); }
     double acc0 = 0.0, acc1 = 0.0;
     int cnt = 0;
     for (int i = x0; i < x1; ++i) {
@@ -840,20 +844,16 @@ __global__ __launch_bounds__(256) void nesma_kernel(NesmaArgs A)
             const u64 ok0 = T.similar(np_rowsum_group(S0, nt, j));           // 8 identical bits per lane group
             const u64 ok1 = L > 8 ? T.similar(np_rowsum_group(S1, nt, j)) : 0ull;
             __builtin_amdgcn_wave_barrier();
-            unsigned vm = 0;                                                 // bit r: neighbour r of the run is similar
-#pragma unroll
-            for (int r = 0; r < 8; ++r) vm |= (unsigned)((ok0 >> (8 * r)) & 1ull) << r;
-#pragma unroll
-            for (int r = 8; r < 2 * MET2_NESMA_HW; ++r) vm |= (unsigned)((ok1 >> (8 * (r - 8))) & 1ull) << r;
-            vm &= (1u << L) - 1u;
-            cnt += __builtin_popcount(vm);
+            const u64 v0 = ok0 & live0, v1 = ok1 & live1;                    // bit 8 r: neighbour r (8 + r) of the run is similar
+            cnt += __builtin_popcountll(v0) + __builtin_popcountll(v1);
 #pragma unroll
             for (int t = 0; t < STEPS; ++t) {
                 if (PACK == 1) {
-                    if ((vm >> t) & 1u) { acc0 += nb0[t]; if (NE > 1) acc1 += nb1[t]; }
+                    if (((t < 8 ? v0 : v1) >> (8 * (t & 7))) & 1ull) { acc0 += nb0[t]; if (NE > 1) acc1 += nb1[t]; }
                 } else {
-                    if ((vm >> (2 * t)) & 1u) acc0 += nb0[t];
-                    if ((vm >> (2 * t + 1)) & 1u) acc0 += from_upper_half(nb0[t]);
+                    const int ra = 2 * t, rb = 2 * t + 1;
+                    if (((ra < 8 ? v0 : v1) >> (8 * (ra & 7))) & 1ull) acc0 += nb0[t];
+                    if (((rb < 8 ? v0 : v1) >> (8 * (rb & 7))) & 1ull) acc0 += from_upper_half(nb0[t]);
                 }
             }
         }
@@ -1179,9 +1179,11 @@ extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
     const dim3 grid((unsigned)((((nvox + 3) / 4 + 7) / 8) * 8)), block(256);      // a multiple of 8 for the XCD remap
     A.srow = ((nt + 23) / 32) * 32 + 8;
     const size_t lds = sizeof(double) * 4 * 2 * MET2_NESMA_HW * (size_t)A.srow;
-    if (nt <= 32)      hipLaunchKernelGGL((nesma_kernel<1, 2>), grid, block, lds, s, A);
-    else if (nt <= 64) hipLaunchKernelGGL((nesma_kernel<1, 1>), grid, block, lds, s, A);
-    else               hipLaunchKernelGGL((nesma_kernel<2, 1>), grid, block, lds, s, A);
+    if (nt == 32)      hipLaunchKernelGGL((nesma_kernel<1, 2, 32>), grid, block, lds, s, A);
+    else if (nt < 32)  hipLaunchKernelGGL((nesma_kernel<1, 2, 0>), grid, block, lds, s, A);
+    else if (nt == 48) hipLaunchKernelGGL((nesma_kernel<1, 1, 48>), grid, block, lds, s, A);
+    else if (nt <= 64) hipLaunchKernelGGL((nesma_kernel<1, 1, 0>), grid, block, lds, s, A);
+    else               hipLaunchKernelGGL((nesma_kernel<2, 1, 0>), grid, block, lds, s, A);
     HIPCHK(hipGetLastError());
     return MET2_OK;
 }
