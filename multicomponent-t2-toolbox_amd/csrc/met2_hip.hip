@@ -221,6 +221,7 @@ struct FitArgs {
     const double *Bfa;    // [nfa][n][n]
     const double *kband;  // [5][64]
     const double *lband;  // [5][64]
+    const double *Kd;     // [n][n] dense L^T L
     const double *lam_grid;
     const double *t2s;    // [n]
     const double *data;   // [nvox][m]
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
     int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri;
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -469,6 +470,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
             const double km = bcast(b, 0);
             b = b / km;
             NnlsState<NB> st; st.itmax_hit = 0;
+            MET2_CYC_INIT(st);
+            MET2_CYC_BEGIN(c_vox);
             nnls_reset<NB>(st);
             project<NB>(S, b, lane, st.h);
             double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
@@ -571,6 +574,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
             }
             if (st.itmax_hit & 1) stat |= MET2_ST_ITMAX;
             if (st.itmax_hit & 2) stat |= MET2_ST_KOVERFLOW;
+            MET2_CYC_END(0, c_vox);
+            MET2_CYC_FLUSH(st);
 
             // ---- epilogue: un-normalise (motor:153-155) + metrics (motor:448-468)
             double xs[NB];
@@ -968,6 +973,7 @@ struct met2_plan {
     double *dB = nullptr;       // [nfa][nt2][nt2]
     double *dKband = nullptr;   // [5][64]
     double *dLband = nullptr;   // [5][64]
+    double *dKd = nullptr;      // [n_t2][n_t2] dense L^T L (row loads of the warm-start refactorisation)
     double *dLam = nullptr;     // [nlam]
     double *dT2 = nullptr;      // [nt2]
     int nlam = 0;
@@ -1267,6 +1273,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dB, sizeof(double) * (size_t)n_fa * n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 128));
+    HIPCHK(hipMalloc(&p->dKd, sizeof(double) * (size_t)n_t2 * n_t2));
+    HIPCHK(hipMemset(p->dKd, 0, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 8)));
     HIPCHK(hipEventCreate(&p->ev0));
@@ -1297,7 +1305,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     (void)hipSetDevice(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dKband, p->dLband, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
+    void *bufs[] = {p->dD, p->dB, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
     for (void *b : bufs) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1405,6 +1413,7 @@ int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
     HIPCHK(hipSetDevice(p->opt.device));
     HIPCHK(hipMemcpy(p->dKband, kb.data(), sizeof(double) * 5 * 128, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->dLband, lb.data(), sizeof(double) * 5 * 128, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dKd, K.data(), sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
     p->Lhost.assign(L, L + (size_t)n * n);
     p->log_detL = log(det_lu(n, L));
     p->have_pen = true;
@@ -1498,6 +1507,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     if (!p->have_pen) {   // plain NNLS never touches the bands, but the kernel loads them
         HIPCHK(hipMemsetAsync(p->dKband, 0, sizeof(double) * 5 * 128, s));
         HIPCHK(hipMemsetAsync(p->dLband, 0, sizeof(double) * 5 * 128, s));
+        HIPCHK(hipMemsetAsync(p->dKd, 0, sizeof(double) * (size_t)p->n_t2 * p->n_t2, s));
     }
     if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 128, s));
     SortBufs sb = sort_bufs(p);
@@ -1525,7 +1535,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
     A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
     A.log_detL = p->log_detL;
-    A.Dfa = p->dD; A.Bfa = p->dB; A.kband = p->dKband; A.lband = p->dLband; A.lam_grid = p->dLam; A.t2s = p->dT2;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
     A.data = data; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     HIPCHK(hipEventRecord(p->ev0, s));
@@ -1552,6 +1562,12 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     p->timed = true;
     if (dbg) {
         HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit kernel done\n");
+#ifdef MET2_CYCSTATS
+        unsigned long long cy[8];
+        HIPCHK(hipMemcpyFromSymbol(cy, HIP_SYMBOL(met2::g_cyc), sizeof(cy)));
+        fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | warm solves=%llu sum k=%llu outer passes=%llu\n",
+                cy[0], cy[1], cy[2], cy[3], cy[4], cy[5], cy[6], cy[7]);
+#endif
 #ifdef MET2_LOOPSTATS
         int ls[8];
         HIPCHK(hipMemcpyFromSymbol(ls, HIP_SYMBOL(met2::g_loopstats), sizeof(ls)));

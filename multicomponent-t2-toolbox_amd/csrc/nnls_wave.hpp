@@ -31,8 +31,24 @@ __device__ int g_loopstats[8];
 #define MET2_STAT(slot, v)
 #endif
 
+#ifdef MET2_CYCSTATS
+__device__ unsigned long long g_cyc[8];
+#define MET2_CYC_BEGIN(var) const unsigned long long var = __builtin_readcyclecounter()
+#define MET2_CYC_END(slot, var) st.cyc[slot] += __builtin_readcyclecounter() - var
+#define MET2_CYC_ADD(slot, v) st.cyc[slot] += (unsigned long long)(v)
+#define MET2_CYC_INIT(st) do { for (int q_ = 0; q_ < 8; ++q_) st.cyc[q_] = 0; } while (0)
+#define MET2_CYC_FLUSH(st) do { if (lane_id() == 0) for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_cyc[q_], st.cyc[q_]); } while (0)
+#else
+#define MET2_CYC_BEGIN(var)
+#define MET2_CYC_END(slot, var)
+#define MET2_CYC_ADD(slot, v)
+#define MET2_CYC_INIT(st)
+#define MET2_CYC_FLUSH(st)
+#endif
+
 struct WaveShared {
     const double *B;    // [n][bstride]
+    const double *K;    // [n][n] dense L^T L in global memory (fit kernel only)
     const double *D;    // [m][dstride]
     double *R;          // this wave's LDS region
     int n, m, bstride, dstride, kmax;
@@ -57,6 +73,9 @@ struct NnlsState {
     int k;             // |P|                (uniform)
     u64 P[NB];         // passive-set mask   (uniform)
     int itmax_hit;     // uniform flags: bit0 iteration cap reached, bit1 passive set hit the capacity kmax < n
+#ifdef MET2_CYCSTATS
+    unsigned long long cyc[8];
+#endif
 };
 
 __device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // entry (i,c) at row_base + c
@@ -453,11 +472,15 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
+    MET2_CYC_BEGIN(c_in0);
     if (warm && st.k > 0 && !nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
+    MET2_CYC_END(2, c_in0);
     for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows) break;
         double w[NB];
+        MET2_CYC_BEGIN(c_du);
         dual<NB>(S, bd, st, lam, lane, w);
+        MET2_CYC_END(3, c_du);
         if (st.k >= S.kmax) {
             // capacity of the fast path reached: if a variable still wants to enter, the voxel is redone with kmax = n
             double vmax = -1.0;
@@ -471,6 +494,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
 #pragma unroll
         for (int b = 0; b < NB; ++b) rejected[b] = 0ull;
         bool accepted = false;
+        MET2_CYC_BEGIN(c_ap);
         for (int tries = 0; tries < 64 * NB; ++tries) {      // each failed try rejects one more bin
             bool cand[NB];
             double val[NB], vmax = -1.0;
@@ -490,8 +514,13 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
             set_bit<NB>(rejected, t);
             MET2_STAT(0, tries + 1);
         }
+        MET2_CYC_END(4, c_ap);
         if (!accepted) break;
-        if (!nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; break; }
+        MET2_CYC_BEGIN(c_in);
+        const bool inner_ok = nnls_inner<NB>(S, st, iter, itmax, lane);
+        MET2_CYC_END(2, c_in);
+        MET2_CYC_ADD(7, 1);
+        if (!inner_ok) { st.itmax_hit |= 1; break; }
         MET2_STAT(2, outer + 1);
         MET2_STAT(3, iter);
     }
@@ -503,6 +532,107 @@ __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 #pragma unroll
     for (int b = 0; b < NB; ++b) { st.x[b] = 0.0; st.y[b] = 0.0; st.rinv[b] = 0.0; st.ord[b] = 0; st.pos[b] = -1; st.P[b] = 0ull; }
     st.k = 0;
+}
+
+// 1/sqrt(d) to fp64 accuracy from v_rsq_f64 and two Newton steps (d > 0, normal range)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    double e = fma(-hd * r, r, 0.5);
+    r = fma(r, e, r);
+    e = fma(-hd * r, r, 0.5);
+    return fma(r, e, r);
+}
+
+// Rebuild R, 1/diag and y = R^-T h_P for the CURRENT passive set and pivot order at a new lambda.
+// Row-by-row (left-looking) Cholesky: row i of R is  (G[ord_i][ord_c] - sum_{j<i} R[j][i] R[j][c]) / R[i][i]  with
+// lane <-> column c, so a row costs i independent LDS row reads + FMAs (issued four at a time) instead of the i
+// dependent substitution steps, reductions, sqrt and divisions of appending column i; the factor R[j][i] is lane i
+// of the row just read.  The B and K rows of the next pivot are fetched while the current row is reduced, and
+// y comes out of the same sweep (one elimination step per finished row).
+// Returns false -- R is then unusable, ord/pos/P/k/x are untouched -- when a pivot falls under the independence
+// threshold of try_append; the caller re-appends column by column, which drops such columns.
+template <int NB>
+__device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
+{
+    const int k = st.k, kmax = S.kmax, n = S.n;
+    int clc[NB], jc[NB];
+    double g[NB], gbn[NB], gkn[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        clc[b] = min(pl, k - 1);                                        // in-row column for the unpredicated row reads
+        jc[b] = min(pl, n - 1);
+        const double hh = gatherN<NB>(st.h, st.ord[b]);
+        g[b] = (pl < k) ? hh : 0.0;
+    }
+    int t = bcastN_i<NB>(st.ord, 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { gbn[b] = S.B[t * S.bstride + jc[b]]; gkn[b] = S.K[t * n + jc[b]]; }
+    int rbi = 0;                                                        // row_base(i)
+    bool bad = false;
+    for (int i = 0; i < k; ++i) {
+        double gb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gb[b] = fma(lam, gkn[b], gbn[b]);                                        // G[.][ord_i], bin-indexed
+        t = bcastN_i<NB>(st.ord, min(i + 1, k - 1));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { gbn[b] = S.B[t * S.bstride + jc[b]]; gkn[b] = S.K[t * n + jc[b]]; }
+        double a[NB], a2[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(gb, st.ord[b]); a2[b] = 0.0; }                      // A[i][c]
+        const double gdiag = bcastN<NB>(a, i);
+        int rbj = 0, j = 0;
+        for (; j + 4 <= i; j += 4) {
+            const int r0 = rbj, r1 = r0 + kmax - j - 1, r2 = r1 + kmax - j - 2, r3 = r2 + kmax - j - 3;
+            double q0[NB], q1[NB], q2[NB], q3[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { q0[b] = S.R[r0 + clc[b]]; q1[b] = S.R[r1 + clc[b]]; q2[b] = S.R[r2 + clc[b]]; q3[b] = S.R[r3 + clc[b]]; }
+            const double s0 = bcastN<NB>(q0, i), s1 = bcastN<NB>(q1, i), s2 = bcastN<NB>(q2, i), s3 = bcastN<NB>(q3, i);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                a[b] = fma(-s0, q0[b], a[b]); a2[b] = fma(-s1, q1[b], a2[b]);
+                a[b] = fma(-s2, q2[b], a[b]); a2[b] = fma(-s3, q3[b], a2[b]);
+            }
+            rbj = r3 + kmax - j - 4;
+        }
+        for (; j < i; ++j) {
+            double q0[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) q0[b] = S.R[rbj + clc[b]];
+            const double s0 = bcastN<NB>(q0, i);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, q0[b], a[b]);
+            rbj += kmax - j - 1;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a[b] += a2[b];
+        const double d = bcastN<NB>(a, i);
+        bad = bad || !(d > 1e-14 * gdiag);
+        const double rinv = rsqrt_nr(d);
+        const double yi = bcastN<NB>(g, i) * rinv;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            const double r = a[b] * rinv;                               // lane i: d * rinv = R[i][i]
+            if (pl >= i && pl < k) S.R[rbi + pl] = r;
+            g[b] = (pl > i) ? fma(-r, yi, g[b]) : g[b];
+        }
+        __builtin_amdgcn_wave_barrier();
+        rbi += kmax - i - 1;
+    }
+    if (bad) return false;
+    // lane p: 1 / R[p][p] and y_p = g_p / R[p][p] (g_p is final once rows < p are eliminated)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        const double dg = (pl < k) ? S.R[row_base(pl, kmax) + pl] : 1.0;
+        const double ri = 1.0 / dg;
+        st.rinv[b] = (pl < k) ? ri : st.rinv[b];
+        st.y[b] = (pl < k) ? g[b] * ri : st.y[b];
+    }
+    return true;
 }
 
 // cold-start solve; on return st.x is the solution
@@ -522,17 +652,22 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
 {
     const int kold = st.k;
     if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
-    int ordold[NB];
+    MET2_CYC_BEGIN(c_ref);
+    MET2_CYC_ADD(5, 1); MET2_CYC_ADD(6, kold);
+    if (!refactor<NB>(S, bd, st, lam, lane)) {
+        int ordold[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { ordold[b] = st.ord[b]; st.pos[b] = -1; st.P[b] = 0ull; }
-    st.k = 0;
-    for (int p = 0; p < kold; ++p) {
-        const int t = bcastN_i<NB>(ordold, p);
-        if (!try_append<NB>(S, bd, st, lam, t, lane, true)) {     // column became dependent: drop it
+        for (int b = 0; b < NB; ++b) { ordold[b] = st.ord[b]; st.pos[b] = -1; st.P[b] = 0ull; }
+        st.k = 0;
+        for (int p = 0; p < kold; ++p) {
+            const int t = bcastN_i<NB>(ordold, p);
+            if (!try_append<NB>(S, bd, st, lam, t, lane, true)) {     // column became dependent: drop it
 #pragma unroll
-            for (int b = 0; b < NB; ++b) if (lane + 64 * b == t) st.x[b] = 0.0;
+                for (int b = 0; b < NB; ++b) if (lane + 64 * b == t) st.x[b] = 0.0;
+            }
         }
     }
+    MET2_CYC_END(1, c_ref);
     nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
 }
 
