@@ -15,7 +15,10 @@
 // holds the position-indexed quantities (ord[p] = bin at position p, y[p] = (R^-T h_P)[p],
 // 1/R[p][p]).
 //
-// Per wave in LDS: R, packed upper-triangular rows, kmax(kmax+1)/2 doubles.
+// Per wave in LDS: R, upper triangular, packed by COLUMNS (entry (r, c), r <= c, at c(c+1)/2 + r), kmax(kmax+1)/2
+// doubles.  A lane's walk down its own column is then a run of consecutive addresses (ds_read2 with immediate
+// offsets in the refactorisation and the substitutions) and lanes of neighbouring columns never share a bank
+// (triangular numbers are distinct mod 32).
 // B (n x n) and D (m x n) are read through S.B / S.D: LDS copies of the workgroup's flip angle
 // when they fit (NB = 1; odd row stride -> conflict-free rows and columns), global memory (L2)
 // otherwise.
@@ -78,7 +81,8 @@ struct NnlsState {
 #endif
 };
 
-__device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // entry (i,c) at row_base + c
+__device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // row-packed factors of objectives.hpp: entry (i,c) at row_base + c
+__device__ __forceinline__ int col_base(int c) { return (c * (c + 1)) >> 1; }                          // the solver's factor: entry (r,c) at col_base(c) + r
 
 // ---- NB-aware cross-lane helpers (idx / src index bins or positions 0..64*NB-1) ----
 template <int NB>
@@ -188,19 +192,19 @@ __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<
 {
     const int k = st.k;
     double y[NB], ra[NB], rb[NB];
-    int rbl[NB];
+    int cb = col_base(k - 1);                                           // column c of the loop below
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
         y[b] = st.y[b];
-        rbl[b] = row_base(pl, S.kmax);
-        ra[b] = (k > 0 && pl < k - 1) ? S.R[rbl[b] + (k - 1)] : 0.0;     // column k-1
+        ra[b] = (k > 0 && pl < k - 1) ? S.R[cb + pl] : 0.0;             // column k-1
         rb[b] = 0.0;
     }
     int c = k - 1;
     for (; c >= 1; c -= 2) {
+        const int cb1 = cb - c, cb2 = cb1 - (c - 1);                    // col_base(c-1), col_base(c-2)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rb[b] = (pl < c - 1) ? S.R[rbl[b] + (c - 1)] : 0.0; }   // column c-1
+        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rb[b] = (pl < c - 1) ? S.R[cb1 + pl] : 0.0; }   // column c-1
         {
             double t = (NB == 2 && (c >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
             double s = bcast(t, c & 63);
@@ -208,7 +212,7 @@ __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<
             for (int b = 0; b < NB; ++b) y[b] = fma(-ra[b], s, y[b]);        // positions >= c are final
         }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; ra[b] = (c >= 2 && pl < c - 2) ? S.R[rbl[b] + (c - 2)] : 0.0; }   // column c-2
+        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; ra[b] = (c >= 2 && pl < c - 2) ? S.R[cb2 + pl] : 0.0; }   // column c-2
         {
             const int c1 = c - 1;
             double t = (NB == 2 && (c1 >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
@@ -216,6 +220,7 @@ __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<
 #pragma unroll
             for (int b = 0; b < NB; ++b) y[b] = fma(-rb[b], s, y[b]);
         }
+        cb = cb2;
     }
     // c == 0 needs no update (nothing lies above row 0's diagonal entry); c == -1: done
 #pragma unroll
@@ -226,41 +231,41 @@ __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<
 template <int NB>
 __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &st, int p, int lane)
 {
-    const int k = st.k, kmax = S.kmax;
+    const int k = st.k;
     const int tb = bcastN_i<NB>(st.ord, p);
     if (p < k - 1) {
-        // rows above p: shift the entries right of column p one place left (all reads, then all writes)
+        int cbl[NB];                                                    // col_base of the lane's own (old) column
+#pragma unroll
+        for (int b = 0; b < NB; ++b) cbl[b] = col_base(lane + 64 * b);
+        // rows above p: column c+1 moves into column c (all reads of a row, then its writes)
         for (int i = 0; i < p; ++i) {
-            const int rb = row_base(i, kmax);
             double v[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int pl = lane + 64 * b;
-                v[b] = (pl >= p && pl <= k - 2) ? S.R[rb + pl + 1] : 0.0;
+                v[b] = (pl >= p && pl <= k - 2) ? S.R[cbl[b] + pl + 1 + i] : 0.0;       // col_base(pl+1) = col_base(pl) + pl + 1
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int pl = lane + 64 * b;
-                if (pl >= p && pl <= k - 2) S.R[rb + pl] = v[b];
+                if (pl >= p && pl <= k - 2) S.R[cbl[b] + i] = v[b];
             }
         }
         // rows p..k-1: chain of plane rotations, owned index = old column index
-        const int rbp = row_base(p, kmax);
         double carry[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int pl = lane + 64 * b;
-            carry[b] = (pl > p && pl < k) ? S.R[rbp + pl] : 0.0;
+            carry[b] = (pl > p && pl < k) ? S.R[cbl[b] + p] : 0.0;
         }
         double ycar = bcastN<NB>(st.y, p);
         for (int j = p + 1; j < k; ++j) {
-            const int rbj = row_base(j, kmax), rbn = row_base(j - 1, kmax);
             double rowj[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int pl = lane + 64 * b;
-                rowj[b] = (pl >= j && pl < k) ? S.R[rbj + pl] : 0.0;
+                rowj[b] = (pl >= j && pl < k) ? S.R[cbl[b] + j] : 0.0;
             }
             double a = bcastN<NB>(carry, j), bb = bcastN<NB>(rowj, j);
             double c, s, sig;
@@ -273,8 +278,9 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
                 const int pl = lane + 64 * b;
                 double nv = c * carry[b] + s * rowj[b];
                 carry[b] = -s * carry[b] + c * rowj[b];
-                if (pl > j && pl < k) S.R[rbn + pl - 1] = nv;
-                if (pl == j) S.R[rbn + j - 1] = sig;
+                // new entry (j-1, pl-1): col_base(pl-1) = col_base(pl) - pl
+                if (pl > j && pl < k) S.R[cbl[b] - pl + j - 1] = nv;
+                if (pl == j) S.R[cbl[b] - pl + j - 1] = sig;
                 if (pl == j - 1) { st.y[b] = ynew; st.rinv[b] = 1.0 / sig; }
             }
         }
@@ -301,7 +307,7 @@ template <int NB>
 __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int t, int lane,
                                            bool forced = false)
 {
-    const int k = st.k, kmax = S.kmax;
+    const int k = st.k;
     double gb[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -311,23 +317,25 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
     }
     const double gtt = bcastN<NB>(gb, t);
     double g[NB], rv[NB];
+    int cbl[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
+        cbl[b] = col_base(pl);
         double gg = gatherN<NB>(gb, st.ord[b]);                          // position-indexed G[ord_p][t]
         g[b] = (pl < k) ? gg : 0.0;
-        rv[b] = (k > 0 && pl > 0 && pl < k) ? S.R[row_base(0, kmax) + pl] : 0.0;      // row 0
+        rv[b] = (k > 0 && pl > 0 && pl < k) ? S.R[cbl[b]] : 0.0;         // row 0
     }
-    // forward substitution R^T r = g, unrolled by two with two prefetch registers (see back_subst)
+    // forward substitution R^T r = g, unrolled by two with two prefetch registers (see back_subst); a lane walks
+    // down its own column, so the row index is an immediate offset from a fixed per-lane address
     {
         double rw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) rw[b] = 0.0;
         int i = 0;
         for (; i + 1 < k; i += 2) {
-            const int rb1 = row_base(i + 1, kmax), rb2 = row_base(i + 2, kmax);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rw[b] = (pl > i + 1 && pl < k) ? S.R[rb1 + pl] : 0.0; }   // row i+1
+            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rw[b] = (pl > i + 1 && pl < k) ? S.R[cbl[b] + i + 1] : 0.0; }   // row i+1
             {
                 double tt = (NB == 2 && (i >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
                 double s = bcast(tt, i & 63);
@@ -335,7 +343,7 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
                 for (int b = 0; b < NB; ++b) g[b] = fma(-rv[b], s, g[b]);      // positions <= i are final
             }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rv[b] = (i + 2 < k && pl > i + 2 && pl < k) ? S.R[rb2 + pl] : 0.0; }   // row i+2
+            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rv[b] = (i + 2 < k && pl > i + 2 && pl < k) ? S.R[cbl[b] + i + 2] : 0.0; }   // row i+2
             {
                 const int i1 = i + 1;
                 double tt = (NB == 2 && (i1 >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
@@ -362,8 +370,8 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        if (pl < k) S.R[row_base(pl, kmax) + k] = r[b];
-        if (pl == k) { S.R[row_base(k, kmax) + k] = rho; st.rinv[b] = 1.0 / rho; st.y[b] = ynew; st.ord[b] = t; }
+        if (pl < k) S.R[col_base(k) + pl] = r[b];
+        if (pl == k) { S.R[col_base(k) + k] = rho; st.rinv[b] = 1.0 / rho; st.y[b] = ynew; st.ord[b] = t; }
         if (pl == t) st.pos[b] = k;
     }
     __builtin_amdgcn_wave_barrier();
@@ -556,55 +564,59 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 template <int NB>
 __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
-    const int k = st.k, kmax = S.kmax, n = S.n;
-    int clc[NB], jc[NB];
+    const int k = st.k, n = S.n;
+    int cbl[NB], cbc[NB];
+    unsigned jc[NB];
     double g[NB], gbn[NB], gkn[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        clc[b] = min(pl, k - 1);                                        // in-row column for the unpredicated row reads
-        jc[b] = min(pl, n - 1);
+        cbl[b] = col_base(pl);
+        cbc[b] = col_base(min(pl, k - 1));                              // an existing column for the unpredicated reads
+        jc[b] = (unsigned)min(pl, n - 1);
         const double hh = gatherN<NB>(st.h, st.ord[b]);
         g[b] = (pl < k) ? hh : 0.0;
     }
-    int t = bcastN_i<NB>(st.ord, 0);
+    {
+        const int t = bcastN_i<NB>(st.ord, 0);
+        const double *Brow = S.B + t * S.bstride, *Krow = S.K + t * n;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { gbn[b] = S.B[t * S.bstride + jc[b]]; gkn[b] = S.K[t * n + jc[b]]; }
-    int rbi = 0;                                                        // row_base(i)
+        for (int b = 0; b < NB; ++b) { gbn[b] = Brow[jc[b]]; gkn[b] = Krow[jc[b]]; }
+    }
+    int cbi = 0;                                                        // col_base(i)
     bool bad = false;
     for (int i = 0; i < k; ++i) {
         double gb[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) gb[b] = fma(lam, gkn[b], gbn[b]);                                        // G[.][ord_i], bin-indexed
-        t = bcastN_i<NB>(st.ord, min(i + 1, k - 1));
+        {
+            const int t = bcastN_i<NB>(st.ord, min(i + 1, k - 1));
+            const double *Brow = S.B + t * S.bstride, *Krow = S.K + t * n;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { gbn[b] = S.B[t * S.bstride + jc[b]]; gkn[b] = S.K[t * n + jc[b]]; }
+            for (int b = 0; b < NB; ++b) { gbn[b] = Brow[jc[b]]; gkn[b] = Krow[jc[b]]; }
+        }
         double a[NB], a2[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(gb, st.ord[b]); a2[b] = 0.0; }                      // A[i][c]
         const double gdiag = bcastN<NB>(a, i);
-        int rbj = 0, j = 0;
+        // a[c] -= sum_{j<i} R[j][i] R[j][c]: column i (one address for the whole wave) and the lane's own column c,
+        // four consecutive rows per step
+        const double *ci = S.R + cbi;
+        int j = 0;
         for (; j + 4 <= i; j += 4) {
-            const int r0 = rbj, r1 = r0 + kmax - j - 1, r2 = r1 + kmax - j - 2, r3 = r2 + kmax - j - 3;
-            double q0[NB], q1[NB], q2[NB], q3[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { q0[b] = S.R[r0 + clc[b]]; q1[b] = S.R[r1 + clc[b]]; q2[b] = S.R[r2 + clc[b]]; q3[b] = S.R[r3 + clc[b]]; }
-            const double s0 = bcastN<NB>(q0, i), s1 = bcastN<NB>(q1, i), s2 = bcastN<NB>(q2, i), s3 = bcastN<NB>(q3, i);
+            const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                a[b] = fma(-s0, q0[b], a[b]); a2[b] = fma(-s1, q1[b], a2[b]);
-                a[b] = fma(-s2, q2[b], a[b]); a2[b] = fma(-s3, q3[b], a2[b]);
+                const double *cc = S.R + cbc[b] + j;
+                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
+                a[b] = fma(-s2, q2, a[b]); a2[b] = fma(-s3, q3, a2[b]);
             }
-            rbj = r3 + kmax - j - 4;
         }
         for (; j < i; ++j) {
-            double q0[NB];
+            const double s0 = ci[j];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) q0[b] = S.R[rbj + clc[b]];
-            const double s0 = bcastN<NB>(q0, i);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, q0[b], a[b]);
-            rbj += kmax - j - 1;
+            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + j], a[b]);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) a[b] += a2[b];
@@ -616,18 +628,18 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         for (int b = 0; b < NB; ++b) {
             const int pl = lane + 64 * b;
             const double r = a[b] * rinv;                               // lane i: d * rinv = R[i][i]
-            if (pl >= i && pl < k) S.R[rbi + pl] = r;
+            if (pl >= i && pl < k) S.R[cbl[b] + i] = r;
             g[b] = (pl > i) ? fma(-r, yi, g[b]) : g[b];
         }
         __builtin_amdgcn_wave_barrier();
-        rbi += kmax - i - 1;
+        cbi += i + 1;
     }
     if (bad) return false;
     // lane p: 1 / R[p][p] and y_p = g_p / R[p][p] (g_p is final once rows < p are eliminated)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        const double dg = (pl < k) ? S.R[row_base(pl, kmax) + pl] : 1.0;
+        const double dg = (pl < k) ? S.R[cbl[b] + pl] : 1.0;
         const double ri = 1.0 / dg;
         st.rinv[b] = (pl < k) ? ri : st.rinv[b];
         st.y[b] = (pl < k) ? g[b] * ri : st.y[b];
