@@ -82,10 +82,16 @@ __global__ __launch_bounds__(256) void epg_dictionary_kernel(int nte, int nt2, i
     }
 }
 
-__global__ __launch_bounds__(256) void gram_kernel(int nte, int nt2, const double *__restrict__ D, double *__restrict__ B)
+__global__ __launch_bounds__(256) void gram_kernel(int nte, int nt2, const double *__restrict__ D, double *__restrict__ B,
+                                                   double *__restrict__ Dt)
 {
     const double *Df = D + (size_t)blockIdx.x * nte * nt2;
     double *Bf = B + (size_t)blockIdx.x * nt2 * nt2;
+    double *Dtf = Dt + (size_t)blockIdx.x * nte * nt2;          // [t2][te]: the model signal D x reads columns of D
+    for (int idx = threadIdx.x; idx < nt2 * nte; idx += blockDim.x) {
+        int a = idx / nte, e = idx - a * nte;
+        Dtf[idx] = Df[e * nt2 + a];
+    }
     for (int idx = threadIdx.x; idx < nt2 * nt2; idx += blockDim.x) {
         int a = idx / nt2, b = idx - a * nt2;
         double t = 0.0;
@@ -219,6 +225,7 @@ struct FitArgs {
     double log_detL;
     const double *Dfa;    // [nfa][m][n]
     const double *Bfa;    // [nfa][n][n]
+    const double *Dtfa;   // [nfa][n][m]
     const double *kband;  // [5][64]
     const double *lband;  // [5][64]
     const double *Kd;     // [n][n] dense L^T L
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
     int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd;
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.Dt = nullptr; S.dtstride = m;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
                 loaded_fa = fa;
                 __syncthreads();
             }
-        } else { S.B = Bf; S.D = Df; }
+        } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
         for (int taken = 0; taken <= cnt; ++taken) {
             int slot = 0;
             if (lane == 0) slot = atomicAdd(&sI[1], 1);
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
     double *sR = sR0 + (size_t)wave * A.wave_doubles;
     int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = nullptr; S.Dt = nullptr; S.dtstride = m;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -973,6 +980,7 @@ struct met2_plan {
     double *dB = nullptr;       // [nfa][nt2][nt2]
     double *dKband = nullptr;   // [5][64]
     double *dLband = nullptr;   // [5][64]
+    double *dDt = nullptr;      // [n_fa][n_t2][n_te] transposed dictionary
     double *dKd = nullptr;      // [n_t2][n_t2] dense L^T L (row loads of the warm-start refactorisation)
     double *dLam = nullptr;     // [nlam]
     double *dT2 = nullptr;      // [nt2]
@@ -1271,6 +1279,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     p->cus = prop.multiProcessorCount;
     HIPCHK(hipMalloc(&p->dD, sizeof(double) * (size_t)n_fa * n_te * n_t2));
     HIPCHK(hipMalloc(&p->dB, sizeof(double) * (size_t)n_fa * n_t2 * n_t2));
+    HIPCHK(hipMalloc(&p->dDt, sizeof(double) * (size_t)n_fa * n_te * n_t2));
     HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dKd, sizeof(double) * (size_t)n_t2 * n_t2));
@@ -1305,7 +1314,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     (void)hipSetDevice(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
+    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
     for (void *b : bufs) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1316,7 +1325,7 @@ int met2_plan_destroy(met2_plan *p)
 
 static int build_gram(met2_plan *p, hipStream_t s)
 {
-    hipLaunchKernelGGL(gram_kernel, dim3(p->n_fa), dim3(256), 0, s, p->n_te, p->n_t2, p->dD, p->dB);
+    hipLaunchKernelGGL(gram_kernel, dim3(p->n_fa), dim3(256), 0, s, p->n_te, p->n_t2, p->dD, p->dB, p->dDt);
     HIPCHK(hipGetLastError());
     p->have_dict = true;
     return MET2_OK;
@@ -1535,7 +1544,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
     A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
     A.log_detL = p->log_detL;
-    A.Dfa = p->dD; A.Bfa = p->dB; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
     A.data = data; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     HIPCHK(hipEventRecord(p->ev0, s));

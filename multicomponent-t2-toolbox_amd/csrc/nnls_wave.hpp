@@ -52,6 +52,8 @@ __device__ unsigned long long g_cyc[8];
 struct WaveShared {
     const double *B;    // [n][bstride]
     const double *K;    // [n][n] dense L^T L in global memory (fit kernel only)
+    const double *Dt;   // [n][dtstride] transposed D in global memory, or NULL (then columns of D are read)
+    int dtstride;
     const double *D;    // [m][dstride]
     double *R;          // this wave's LDS region
     int n, m, bstride, dstride, kmax;
@@ -384,26 +386,41 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
 template <int NB>
 __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double lam, int lane, double (&w)[NB])
 {
-    double acc[NB];
+    // B x over the passive set, four rows of B in flight per step (the rows come from L2: issued back to back they
+    // overlap their latency, one at a time each step would wait for its own load)
+    double acc[NB], acc2[NB], xp[NB];
+    unsigned jc[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = 0.0;
+    for (int b = 0; b < NB; ++b) {
+        acc[b] = 0.0; acc2[b] = 0.0;
+        jc[b] = (unsigned)min(lane + 64 * b, S.n - 1);
+        xp[b] = gatherN<NB>(st.x, st.ord[b]);                            // x by position
+    }
     const int k = st.k;
-    for (int p = 0; p < k; ++p) {
-        int i = bcastN_i<NB>(st.ord, p);
-        double xi = bcastN<NB>(st.x, i);
+    for (int p = 0; p < k; p += 4) {
+        double v[4][NB], xs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pp = min(p + q, k - 1);
+            const double *Brow = S.B + bcastN_i<NB>(st.ord, pp) * S.bstride;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) v[q][b] = Brow[jc[b]];
+            xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int j = lane + 64 * b;
-            double bv = (j < S.n) ? S.B[i * S.bstride + j] : 0.0;
-            acc[b] = fma(bv, xi, acc[b]);
+            acc[b] = fma(v[0][b], xs[0], acc[b]); acc2[b] = fma(v[1][b], xs[1], acc2[b]);
+            acc[b] = fma(v[2][b], xs[2], acc[b]); acc2[b] = fma(v[3][b], xs[3], acc2[b]);
         }
     }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] += acc2[b];
     double kx[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) kx[b] = 0.0;
     if (lam != 0.0) band_mul<NB>(bd.kb, st.x, lane, kx);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) w[b] = fma(-lam, kx[b], st.h[b] - acc[b]);
+    for (int b = 0; b < NB; ++b) w[b] = (lane + 64 * b < S.n) ? fma(-lam, kx[b], st.h[b] - acc[b]) : 0.0;
 }
 
 // Lawson-Hanson's secondary loop: from a feasible x and a factor consistent with (P, lambda), move to
@@ -687,8 +704,29 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
 template <int NB>
 __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsState<NB> &st, int lane)
 {
+    const int k = st.k;
+    if (S.Dt) {
+        // rows of D^T: coalesced, four in flight per step
+        double acc = 0.0, acc2 = 0.0, xp[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xp[b] = gatherN<NB>(st.x, st.ord[b]);
+        const unsigned ec = (unsigned)min(lane, S.m - 1);
+        for (int p = 0; p < k; p += 4) {
+            double v[4], xs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pp = min(p + q, k - 1);
+                const double *Drow = S.Dt + bcastN_i<NB>(st.ord, pp) * S.dtstride;
+                v[q] = Drow[ec];
+                xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
+            }
+            acc = fma(v[0], xs[0], acc); acc2 = fma(v[1], xs[1], acc2);
+            acc = fma(v[2], xs[2], acc); acc2 = fma(v[3], xs[3], acc2);
+        }
+        return acc + acc2;
+    }
     double acc = 0.0;
-    for (int p = 0; p < st.k; ++p) {
+    for (int p = 0; p < k; ++p) {
         int i = bcastN_i<NB>(st.ord, p);
         double xi = bcastN<NB>(st.x, i);
         double dv = (lane < S.m) ? S.D[lane * S.dstride + i] : 0.0;
@@ -712,15 +750,26 @@ __device__ __forceinline__ void project(const WaveShared &S, double bvec, int la
 {
 #pragma unroll
     for (int b = 0; b < NB; ++b) h[b] = 0.0;
-    for (int e = 0; e < S.m; ++e) {
-        double be = bcast(bvec, e);
+    unsigned jc[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int j = lane + 64 * b;
-            double dv = (j < S.n) ? S.D[e * S.dstride + j] : 0.0;
-            h[b] = fma(dv, be, h[b]);
+    for (int b = 0; b < NB; ++b) jc[b] = (unsigned)min(lane + 64 * b, S.n - 1);
+    for (int e = 0; e < S.m; e += 4) {                     // four rows of D in flight per step
+        double dv[4][NB], be[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ee = min(e + q, S.m - 1);
+            const double *Drow = S.D + ee * S.dstride;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) dv[q][b] = Drow[jc[b]];
+            be[q] = (e + q < S.m) ? bcast(bvec, ee) : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) h[b] = fma(dv[q][b], be[q], h[b]);
     }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) h[b] = (lane + 64 * b < S.n) ? h[b] : 0.0;
 }
 
 // ||L x||^2 for the bin-indexed x (L as 5 diagonals)
