@@ -397,6 +397,7 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
         xp[b] = gatherN<NB>(st.x, st.ord[b]);                            // x by position
     }
     const int k = st.k;
+#pragma clang loop unroll(disable)
     for (int p = 0; p < k; p += 4) {
         double v[4][NB], xs[4];
 #pragma unroll
@@ -620,6 +621,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         // four consecutive rows per step
         const double *ci = S.R + cbi;
         int j = 0;
+#pragma clang loop unroll(disable)
         for (; j + 4 <= i; j += 4) {
             const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
 #pragma unroll
@@ -711,6 +713,7 @@ __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsSt
 #pragma unroll
         for (int b = 0; b < NB; ++b) xp[b] = gatherN<NB>(st.x, st.ord[b]);
         const unsigned ec = (unsigned)min(lane, S.m - 1);
+#pragma clang loop unroll(disable)
         for (int p = 0; p < k; p += 4) {
             double v[4], xs[4];
 #pragma unroll
@@ -753,6 +756,7 @@ __device__ __forceinline__ void project(const WaveShared &S, double bvec, int la
     unsigned jc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) jc[b] = (unsigned)min(lane + 64 * b, S.n - 1);
+#pragma clang loop unroll(disable)
     for (int e = 0; e < S.m; e += 4) {                     // four rows of D in flight per step
         double dv[4][NB], be[4];
 #pragma unroll
