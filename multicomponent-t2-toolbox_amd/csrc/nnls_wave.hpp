@@ -545,7 +545,6 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
         MET2_CYC_BEGIN(c_in);
         const bool inner_ok = nnls_inner<NB>(S, st, iter, itmax, lane);
         MET2_CYC_END(2, c_in);
-        MET2_CYC_ADD(7, 1);
         if (!inner_ok) { st.itmax_hit |= 1; break; }
         MET2_STAT(2, outer + 1);
         MET2_STAT(3, iter);
@@ -684,7 +683,6 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     const int kold = st.k;
     if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
-    MET2_CYC_ADD(5, 1); MET2_CYC_ADD(6, kold);
     if (!refactor<NB>(S, bd, st, lam, lane)) {
         int ordold[NB];
 #pragma unroll

@@ -15,51 +15,70 @@ __device__ __forceinline__ double wave_prod(double v)
     return (bcast(v, 0) * bcast(v, 16)) * (bcast(v, 32) * bcast(v, 48));
 }
 
-// Upper Cholesky factor U (A = U^T U) of A = beta*B + (beta*lam)*K, rows packed into S.R
-// (needs kmax == n).  A lane owns columns lane + 64 b.  Returns false when a pivot is not positive
-// (scipy raises LinAlgError there).
+// Upper Cholesky factor U (A = U^T U) of A = beta*B + (beta*lam)*K, packed by columns into S.R like the solver's
+// factor (entry (r, c) at col_base(c) + r; needs kmax == n).  Row by row as in refactor(): a lane owns columns
+// lane + 64 b, row j costs j independent LDS reads + FMAs in batches of four, the rows of B and of the dense K for
+// the next pivot are in flight meanwhile.  Returns false when a pivot is not positive (scipy raises LinAlgError there).
 template <int NB>
 __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
 {
-    const int n = S.n, kmax = S.kmax;
+    const int n = S.n;
     const double bl = beta * lam;
-    double diag[NB];
+    int cbl[NB], cbc[NB];
+    unsigned jc[NB];
+    double diag[NB], gbn[NB], gkn[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) diag[b] = 1.0;
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        cbl[b] = col_base(pl);
+        cbc[b] = col_base(min(pl, n - 1));
+        jc[b] = (unsigned)min(pl, n - 1);
+        diag[b] = 1.0;
+        gbn[b] = S.B[jc[b]]; gkn[b] = S.K[jc[b]];
+    }
+    int cbj = 0;                                                        // col_base(j)
     for (int j = 0; j < n; ++j) {
-        double a[NB], colj[NB], s[NB];
+        double a[NB], a2[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int c = lane + 64 * b;
-            a[b] = (c < n) ? beta * S.B[j * S.bstride + c] : 0.0;
-            a[b] = fma(bl, band_pick(bd.kb[b], j - c), a[b]);          // A[j][c]
-            colj[b] = (c < j) ? S.R[row_base(c, kmax) + j] : 0.0;      // U[c][j] of the rows already done
-            s[b] = 0.0;
+        for (int b = 0; b < NB; ++b) { a[b] = fma(bl, gkn[b], beta * gbn[b]); a2[b] = 0.0; }                  // A[j][c]
+        {
+            const int jn = min(j + 1, n - 1);
+            const double *Brow = S.B + jn * S.bstride, *Krow = S.K + jn * n;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { gbn[b] = Brow[jc[b]]; gkn[b] = Krow[jc[b]]; }
         }
-        for (int k = 0; k < j; ++k) {
-            const double ukj = bcastN<NB>(colj, k);
-            const int rb = row_base(k, kmax);
+        const double *cj = S.R + cbj;
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 4 <= j; k += 4) {
+            const double s0 = cj[k], s1 = cj[k + 1], s2 = cj[k + 2], s3 = cj[k + 3];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int c = lane + 64 * b;
-                double uki = (c >= j && c < n) ? S.R[rb + c] : 0.0;
-                s[b] = fma(ukj, uki, s[b]);
+                const double *cc = S.R + cbc[b] + k;
+                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
+                a[b] = fma(-s2, q2, a[b]); a2[b] = fma(-s3, q3, a2[b]);
             }
         }
-        double v[NB];
+        for (; k < j; ++k) {
+            const double s0 = cj[k];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) v[b] = a[b] - s[b];
-        const double d = bcastN<NB>(v, j);
+            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + k], a[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a[b] += a2[b];
+        const double d = bcastN<NB>(a, j);
         if (!(d > 0.0)) return false;
-        const double ujj = sqrt(d);
+        const double rinv = rsqrt_nr(d);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int c = lane + 64 * b;
-            double u = (c == j) ? ujj : v[b] / ujj;
-            if (c >= j && c < n) S.R[row_base(j, kmax) + c] = u;
-            if (c == j) diag[b] = ujj;
+            const double u = a[b] * rinv;                               // lane j: d * rinv = U[j][j]
+            if (c >= j && c < n) S.R[cbl[b] + j] = u;
+            if (c == j) diag[b] = u;
         }
         __builtin_amdgcn_wave_barrier();
+        cbj += j + 1;
     }
     double dp = 1.0;
 #pragma unroll
@@ -72,18 +91,19 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
 template <int NB>
 __device__ __forceinline__ void upper_times(const WaveShared &S, const double (&f)[NB], int lane, double (&out)[NB])
 {
-    const int n = S.n, kmax = S.kmax;
-    int rbl[NB];
+    const int n = S.n;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { rbl[b] = row_base(lane + 64 * b, kmax); out[b] = 0.0; }
+    for (int b = 0; b < NB; ++b) out[b] = 0.0;
+    int cbj = 0;
     for (int j = 0; j < n; ++j) {
         const double fj = bcastN<NB>(f, j);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int i = lane + 64 * b;
-            double u = (i <= j && i < n) ? S.R[rbl[b] + j] : 0.0;
+            double u = (i <= j) ? S.R[cbj + i] : 0.0;                   // column j: rows 0..j
             out[b] = fma(u, fj, out[b]);
         }
+        cbj += j + 1;
     }
 }
 
@@ -102,13 +122,28 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
     const double ED = 0.5 * sse_of<NB>(S, st, b, lane);
     const double EW = 0.5 * seminorm2<NB>(bd, st.x, n, lane);
     double det_u;
+#ifdef MET2_CYCSTATS
+    NnlsState<NB> &stw = const_cast<NnlsState<NB> &>(st);
+    const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
     if (!chol_full<NB>(S, bd, beta, x, lane, det_u)) { bc.failed = 1; return NAN; }
+#ifdef MET2_CYCSTATS
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    stw.cyc[5] += c1 - c0;
+#endif
     double uf[NB];
     upper_times<NB>(S, st.x, lane, uf);
+#ifdef MET2_CYCSTATS
+    const unsigned long long c2 = __builtin_readcyclecounter();
+    stw.cyc[6] += c2 - c1;
+#endif
     double term = 0.0;
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) term += (lane + 64 * bb < n) ? log(1.0 + erf((1.0 / sqrt(2.0)) * uf[bb])) : 0.0;
     const double series = wave_sum(term);
+#ifdef MET2_CYCSTATS
+    stw.cyc[7] += __builtin_readcyclecounter() - c2;
+#endif
     const double PI = M_PI;
     double cost1 = beta * ED + beta * x * EW + log(det_u) - (n / 2.0) * log(PI / 2.0) - series;
     double cost2 = (m / 2.0) * log(2.0 * PI) - (m / 2.0) * log(beta) + (n / 2.0) * log(PI) - (n / 2.0) * log(2 * beta * x) - bc.log_detL;
