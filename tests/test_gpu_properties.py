@@ -90,6 +90,65 @@ def test_nnls_kkt_full_size(pkg, big):
     assert ((w / scale).abs() * (x > 0)).max() < 1e-9
 
 
+def test_x2_tikhonov_kkt_full_size(pkg, big):
+    # the returned spectrum must be THE minimiser of ||D x - b||^2 + lam ||L x||^2, x >= 0 at the returned lambda:
+    # optimality conditions of the regularised problem on every voxel of the full volume (the last solve of each
+    # voxel is a warm start through the row-Cholesky refactorisation, so this exercises that path 1 048 576 times)
+    import torch
+    plan, data, out = big
+    motor = importlib.import_module(PKG + ".motor")
+    D = torch.as_tensor(plan.get_dictionary()[:, :, 0], device="cuda")
+    L = torch.as_tensor(motor.create_Laplacian_matrix(60, 2), device="cuda")
+    K = L.T @ L
+    worst_pos, worst_pas = 0.0, 0.0
+    for lo in range(0, data.shape[0], 262_144):
+        b = data[lo:lo + 262_144]; x = out["fsol"][lo:lo + 262_144]; lam = out["lam"][lo:lo + 262_144].unsqueeze(1)
+        w = (b - x @ D.T) @ D - lam * (x @ K)
+        scale = (b @ D).abs().max(dim=1).values.unsqueeze(1)
+        assert (x >= 0).all()
+        worst_pos = max(worst_pos, (w / scale).max().item())
+        worst_pas = max(worst_pas, ((w / scale).abs() * (x > 0)).max().item())
+    assert worst_pos < 1e-9 and worst_pas < 1e-9, (worst_pos, worst_pas)
+
+
+def test_dependent_columns_take_the_fallback(pkg):
+    # two identical dictionary columns: at lambda > 0 (penalty I) both may sit in the passive set, at a smaller lambda
+    # the warm-started factor meets a pivot under the independence threshold and the solver must fall back to
+    # re-appending column by column (dropping one).  The fitted signal and the regularised solution stay unique.
+    import torch
+    from oracle import oracle
+    oracle.build()
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2 = 32, 60
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    D = oracle.create_met2_design_matrix_epg(nt2, T2s, T1s, nte, 10.0, 150.0, 3000.0).copy()
+    D[:, 21] = D[:, 20]; D[:, 41] = D[:, 40]
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.set_dictionary(np.ascontiguousarray(D[:, :, None])).set_t2_grid(T2s).set_penalty("I")
+    data, _, _ = synth.make_voxels(3000, nte=nte, seed=77, device="cuda")
+    out = plan.fit("X2", data, want_lambda=True)
+    st = out["status"].cpu().numpy()
+    assert (st & 1).all() and not (st & (4 | 8)).any()
+    d = data.cpu().numpy()
+    L = oracle.penalty(nt2, "I", T2s)
+    fs, sg, rg, so = oracle.fit_batch("X2", D[None], L, d, np.zeros(3000), np.ones(3000), nthreads=8)
+    got = out["fsol"].cpu().numpy(); gs = out["sig"].cpu().numpy()
+    e = np.max(np.abs(got - fs), axis=1) / np.max(np.abs(fs), axis=1)
+    es = np.max(np.abs(gs - sg), axis=1) / np.max(np.abs(sg), axis=1)
+    assert np.mean(e < 1e-5) > 0.998 and np.mean(es < 1e-5) > 0.998, (e.max(), es.max())
+    # identical columns carry identical coefficients at the regularised optimum
+    assert np.allclose(got[:, 20], got[:, 21], rtol=1e-6, atol=1e-9 * got.max())
+    # a lambda grid that steps from 1e-2 straight down to 0: the warm start carries both twins into lambda = 0, where
+    # the second one's pivot is exactly dependent -> refactor() reports it and the column-by-column path drops it
+    grid = np.array([1e-2, 0.0, 1e-1, 1e-3, 1e-4, 1e-5, 1e-6])
+    plan.set_lambda_grid(grid)
+    out = plan.fit("L_curve", data)
+    fs, sg, rg, so = oracle.fit_batch("L_curve", D[None], L, d, np.zeros(3000), np.ones(3000), lambda_reg=grid, nthreads=8)
+    assert np.array_equal(out["reg"].cpu().numpy(), rg)
+    gs = out["sig"].cpu().numpy()
+    assert np.max(np.abs(gs - sg), axis=1).max() / np.abs(sg).max() < 1e-5
+
+
 def test_edge_cases(pkg):
     import torch
     synth = importlib.import_module(PKG + ".synth")
