@@ -615,6 +615,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
 struct FaArgs {
     int n, m, nfa, np, kmax, waves, wave_doubles;
     const double *Dfa, *Bfa;
+    const double *Kd;         // [n][n], only multiplied by lambda = 0 here (the refactorisation reads its rows)
     const double *data;
     const uint8_t *mask;
     double *fa_index, *km, *resid;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
     double *sR = sR0 + (size_t)wave * A.wave_doubles;
     int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = nullptr; S.Dt = nullptr; S.dtstride = m;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.Dt = nullptr; S.dtstride = m;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -654,8 +655,15 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
         double b[VPW], best_r[VPW], best_km[VPW];
         int best_fa[VPW];
         bool act[VPW];
+        // the passive set and x of a voxel carry over from one flip angle to the next (neighbouring dictionaries give
+        // nearly the same support): each solve is a warm start -- re-factorise, secondary loop, dual check -- instead
+        // of rebuilding the support bin by bin.  NNLS has one minimiser, so only the rounding differs from a cold start.
+        NnlsState<NB> st[VPW];
 #pragma unroll
         for (int vv = 0; vv < VPW; ++vv) {
+            st[vv].itmax_hit = 0;
+            MET2_CYC_INIT(st[vv]);
+            nnls_reset<NB>(st[vv]);
             const int64_t v = v0 + vv;
             const bool in = v < A.nvox;
             b[vv] = (in && lane < m) ? A.data[(size_t)v * m + lane] : 0.0;
@@ -677,16 +685,15 @@ __global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
                 if (!act[vv]) continue;
-                NnlsState<NB> st; st.itmax_hit = 0;
-                project<NB>(S, b[vv], lane, st.h);
-                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
-                const double rn = sqrt(sse_of<NB>(S, st, b[vv], lane));
+                project<NB>(S, b[vv], lane, st[vv].h);
+                nnls_solve_warm<NB>(S, bd, st[vv], 0.0, false, lane);
+                const double rn = sqrt(sse_of<NB>(S, st[vv], b[vv], lane));
                 if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
                 if (rn < best_r[vv]) {        // np.argmin: first minimum wins
                     best_r[vv] = rn; best_fa[vv] = fa;
                     double t = 0.0;
 #pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) t += (lane + 64 * bb < n) ? st.x[bb] : 0.0;
+                    for (int bb = 0; bb < NB; ++bb) t += (lane + 64 * bb < n) ? st[vv].x[bb] : 0.0;
                     best_km[vv] = wave_sum(t);
                 }
             }
@@ -1613,7 +1620,7 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
     A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
-    A.Dfa = p->dD; A.Bfa = p->dB; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.Kd = p->dKd; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
     HIPCHK(hipEventRecord(p->ev0, s));
     if (g.nb == 1) {
