@@ -623,8 +623,8 @@ struct FaArgs {
     int64_t nvox;
 };
 
-template <int VPW, int NB>
-__global__ __launch_bounds__(512) void fa_kernel(FaArgs A)
+template <int VPW, int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -1613,9 +1613,16 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     HIPCHK(hipSetDevice(p->opt.device));
     hipStream_t s = (hipStream_t)stream;
     LaunchGeom g;
-    int rc = fit_geometry(p, MET2_NNLS, g, false);
+    // plain NNLS stops at min(n_t2, n_te) passive bins (Lawson-Hanson's k >= rows test), so the factor needs that
+    // capacity only: 4 KB per wave at nTE = 32 instead of 14.6 KB, and 16 waves share a CU with the staged D and B
+    const int kcap = p->n_te < p->n_t2 ? p->n_te : 0;
+    int rc = fit_geometry(p, MET2_NNLS, g, false, kcap);
     if (rc) return rc;
-    if (g.waves > 8) { g.waves = 8; g.block = 512; g.lds = (int)(sizeof(double) * ((size_t)p->n_t2 * g.np + (size_t)p->n_te * g.np) * (g.stage ? 1 : 0) + sizeof(double) * (size_t)g.wave_doubles * 8 + 64); }
+    const int fa_waves = g.waves >= 16 ? 16 : (g.waves >= 8 ? 8 : g.waves);
+    if (g.waves != fa_waves) {
+        g.waves = fa_waves; g.block = 64 * fa_waves;
+        g.lds = (int)(sizeof(double) * ((size_t)p->n_t2 * g.np + (size_t)p->n_te * g.np) * (g.stage ? 1 : 0) + sizeof(double) * (size_t)g.wave_doubles * fa_waves + 64);
+    }
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
@@ -1623,13 +1630,14 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     A.Dfa = p->dD; A.Bfa = p->dB; A.Kd = p->dKd; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
     HIPCHK(hipEventRecord(p->ev0, s));
-    if (g.nb == 1) {
-        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-        hipLaunchKernelGGL((fa_kernel<4, 1>), dim3(g.grid), dim3(g.block), g.lds, s, A);
-    } else {
-        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-        hipLaunchKernelGGL((fa_kernel<2, 2>), dim3(g.grid), dim3(g.block), g.lds, s, A);
-    }
+#define MET2_FA_LAUNCH(VPW, NB, WAVES)                                                                                   \
+    do {                                                                                                                \
+        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
+        hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES>), dim3(g.grid), dim3(g.block), g.lds, s, A);                       \
+    } while (0)
+    if (g.nb == 1) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16); else MET2_FA_LAUNCH(4, 1, 8); }
+    else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16); else MET2_FA_LAUNCH(2, 2, 8); }
+#undef MET2_FA_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev1, s));
     p->timed = true;
