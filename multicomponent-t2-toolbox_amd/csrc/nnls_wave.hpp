@@ -570,6 +570,14 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return fma(r, e, r);
 }
 
+// 1/d to fp64 accuracy from v_rcp_f64 and two Newton steps (d != 0, normal range)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return fma(r, fma(-d, r, 1.0), r);
+}
+
 // Rebuild R, 1/diag and y = R^-T h_P for the CURRENT passive set and pivot order at a new lambda.
 // Row-by-row (left-looking) Cholesky: row i of R is  (G[ord_i][ord_c] - sum_{j<i} R[j][i] R[j][c]) / R[i][i]  with
 // lane <-> column c, so a row costs i independent LDS row reads + FMAs (issued four at a time) instead of the i

@@ -165,6 +165,10 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
                                                 int lane, int &overflow)
 {
     const int n = S.n, m = S.m, mm = m + 1;
+#ifdef MET2_CYCSTATS
+    NnlsState<NB> &stw = const_cast<NnlsState<NB> &>(st);
+    const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
     const double sse = sse_of<NB>(S, st, b, lane);
     const double rn2 = sse + x * seminorm2<NB>(bd, st.x, n, lane);   // squared residual norm of the augmented system
     bool inS[NB];
@@ -209,6 +213,10 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     }
     if (lane < mm) wl[lane] = (lane == m) ? 1.0 : 0.0;
     __builtin_amdgcn_wave_barrier();
+#ifdef MET2_CYCSTATS
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    stw.cyc[5] += c1 - c0;
+#endif
     // Round-robin ("tournament") ordering: N = mm rounded up to even players, N-1 rounds of N/2 disjoint column
     // pairs; with mm odd the fixed player is a dummy and its pair is skipped.  Every pair gets LP lanes: the
     // lanes of a pair split the k rows, partial inner products meet through LP-wide xor shuffles, and the
@@ -234,7 +242,10 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         for (int rd = 0; rd < N - 1; ++rd) {
             int ca, cb;
             if (ti == 0) { ca = rd; cb = N - 1; }
-            else { ca = (rd + ti) % (N - 1); cb = (rd - ti + (N - 1)) % (N - 1); }
+            else {                                      // (rd +- ti) mod (N-1): both operands are below N-1
+                ca = rd + ti; ca = (ca >= N - 1) ? ca - (N - 1) : ca;
+                cb = rd - ti; cb = (cb < 0) ? cb + (N - 1) : cb;
+            }
             if (ca > cb) { int t = ca; ca = cb; cb = t; }
             const double alpha = mine ? cn2[ca] : 0.0, beta = mine ? cn2[cb] : 0.0;
             double gamma = 0.0;
@@ -246,10 +257,14 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
             // rounding noise (eps * sqrt(big) per entry) that cancellation left in small columns
             const bool rot = mine && !(alpha < floor2 && beta < floor2) && (g2 > 1e-30 * alpha * beta) && (g2 > noise2 * fmax(alpha, beta));
             rotated |= ballot(rot);
+            // rotation parameters through v_rsq_f64 / v_rcp_f64 + Newton steps instead of IEEE sqrt and divisions
+            // (a Jacobi rotation only has to be orthogonal, which cs and sn = cs t are to rounding)
             const double a = beta - alpha, g = 2.0 * gamma;
-            const double hyp = sqrt(a * a + g * g);
-            const double t = (a >= 0.0) ? g / (a + hyp) : g / (a - hyp);     // tan of the rotation angle, |t| <= 1
-            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+            const double h2 = fma(a, a, g * g);
+            const double hyp = (h2 > 0.0) ? h2 * rsqrt_nr(h2) : 0.0;
+            const double den = (a >= 0.0) ? a + hyp : a - hyp;
+            const double t = (den != 0.0) ? g * rcp_nr(den) : 0.0;           // tan of the rotation angle, |t| <= 1
+            const double cs = rsqrt_nr(fma(t, t, 1.0)), sn = cs * t;
             if (rot) {
                 for (int r = sub; r < k; r += LP) {
                     const double ap = A[ca * k + r], aq = A[cb * k + r];
@@ -265,8 +280,14 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
             __builtin_amdgcn_wave_barrier();
         }
         MET2_STAT(6, sweep + 1);
+#ifdef MET2_CYCSTATS
+        stw.cyc[7] += 1;
+#endif
         if (!rotated) break;
     }
+#ifdef MET2_CYCSTATS
+    stw.cyc[6] += __builtin_readcyclecounter() - c1;
+#endif
     double t2 = 0.0;
     for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; t2 = fma(v, v, t2); }
     const double smax = wave_max(lane < mm ? t2 : 0.0);                  // singular values of G = sigma(E)^2
