@@ -1581,7 +1581,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
 #ifdef MET2_CYCSTATS
         unsigned long long cy[8];
         HIPCHK(hipMemcpyFromSymbol(cy, HIP_SYMBOL(met2::g_cyc), sizeof(cy)));
-        fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | bayes: chol | gcv: build=%llu upper_times | sweeps=%llu erf/log | nsweeps=%llu\n",
+        fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | slots 5-7 (bayes: chol, upper_times, erf/log; gcv small path: cycles, evaluations, sweeps; append slot += sum k)=%llu %llu %llu\n",
                 cy[0], cy[1], cy[2], cy[3], cy[4], cy[5], cy[6], cy[7]);
 #endif
 #ifdef MET2_LOOPSTATS

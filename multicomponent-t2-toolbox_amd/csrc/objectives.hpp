@@ -150,6 +150,104 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
     return cost1 + cost2;
 }
 
+// One-sided Jacobi on the k columns of E ((m+1) x k), for supports of at most 32 bins: E V = U Sigma, so after
+// convergence column r holds sigma_r u_r -- its squared norm is an eigenvalue of G = E^T E and its last entry over
+// sigma_r is U[m][r]; no rotation has to be accumulated.  Round-robin ordering over the k columns (k - 1 rounds of
+// up to 16 disjoint pairs instead of the m rounds of the E^T variant); a pair owns four lanes, each keeps its slice
+// of both columns (<= MET2_GCV_ROWS rows) in registers between the inner product and the rotation.
+// Returns trace(Dr G^+ Dr^T) = sum_{kept r} (1 - U[m][r]^2).
+#define MET2_GCV_ROWS 13                                      // ceil((n_te + 1) / 4) for n_te <= 51
+template <int NB>
+__device__ __forceinline__ double gcv_trace_small(const WaveShared &S, const int (&sp)[NB], int k, double sc, int lane, int &nsweep_done)
+{
+    nsweep_done = 0;
+    const int m = S.m, mm = m + 1, mmp = mm | 1;
+    double *Bm = S.R;                                       // column r at Bm + r * mmp, rows 0..m
+    double *cn2 = Bm + k * mmp;                             // [k] squared column norms
+    {
+        const unsigned ec = (unsigned)min(lane, m - 1);
+        for (int r = 0; r < k; r += 4) {
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = min(r + q, k - 1);
+                const double *Drow = S.Dt + bcastN_i<NB>(sp, rr) * S.dtstride;
+                v[q] = Drow[ec];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (r + q < k && lane < mm) Bm[(r + q) * mmp + lane] = (lane < m) ? v[q] : sc;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int odd = k & 1;
+    const int N = k + odd, nreal = N / 2 - odd;             // with k odd the fixed player is a dummy, its pair is skipped
+    const int pi = lane >> 2, sub = lane & 3;
+    const bool mine = pi < nreal;
+    const int ti = pi + odd;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        {
+            double t2 = 0.0;
+            if (lane < k) for (int e = 0; e < mm; ++e) { const double v = Bm[lane * mmp + e]; t2 = fma(v, v, t2); }
+            if (lane < k) cn2[lane] = t2;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double big = wave_max(lane < k ? cn2[lane] : 0.0);
+        const double floor2 = 1e-6 * (2.220446049250313e-16 * (double)k * big);
+        const double noise2 = 16.0 * 4.930380657631324e-32 * big * (double)mm;
+        u64 rotated = 0ull;
+        for (int rd = 0; rd < N - 1; ++rd) {
+            int ca, cb;
+            if (ti == 0) { ca = rd; cb = N - 1; }
+            else {
+                ca = rd + ti; ca = (ca >= N - 1) ? ca - (N - 1) : ca;
+                cb = rd - ti; cb = (cb < 0) ? cb + (N - 1) : cb;
+            }
+            if (ca > cb) { int t = ca; ca = cb; cb = t; }
+            if (!mine) { ca = 0; cb = 0; }
+            double *pa = Bm + ca * mmp + sub, *pb = Bm + cb * mmp + sub;
+            double xa[MET2_GCV_ROWS], xb[MET2_GCV_ROWS];
+            double gamma = 0.0;
+#pragma unroll
+            for (int q = 0; q < MET2_GCV_ROWS; ++q) {
+                const bool in = sub + 4 * q < mm;
+                xa[q] = in ? pa[4 * q] : 0.0; xb[q] = in ? pb[4 * q] : 0.0;
+                gamma = fma(xa[q], xb[q], gamma);
+            }
+            const double alpha = mine ? cn2[ca] : 0.0, beta = mine ? cn2[cb] : 0.0;
+            gamma += __shfl_xor(gamma, 1);
+            gamma += __shfl_xor(gamma, 2);
+            const double g2 = gamma * gamma;
+            const bool rot = mine && !(alpha < floor2 && beta < floor2) && (g2 > 1e-30 * alpha * beta) && (g2 > noise2 * fmax(alpha, beta));
+            rotated |= ballot(rot);
+            const double a = beta - alpha, g = 2.0 * gamma;
+            const double h2 = fma(a, a, g * g);
+            const double hyp = (h2 > 0.0) ? h2 * rsqrt_nr(h2) : 0.0;
+            const double den = (a >= 0.0) ? a + hyp : a - hyp;
+            const double t = (den != 0.0) ? g * rcp_nr(den) : 0.0;
+            const double cs = rsqrt_nr(fma(t, t, 1.0)), sn = cs * t;
+            if (rot) {
+#pragma unroll
+                for (int q = 0; q < MET2_GCV_ROWS; ++q)
+                    if (sub + 4 * q < mm) { pa[4 * q] = cs * xa[q] - sn * xb[q]; pb[4 * q] = sn * xa[q] + cs * xb[q]; }
+                if (sub == 0) { cn2[ca] = alpha - t * gamma; cn2[cb] = beta + t * gamma; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        MET2_STAT(6, sweep + 1);
+        nsweep_done = sweep + 1;
+        if (!rotated) break;
+    }
+    double t2 = 0.0, last = 0.0;
+    if (lane < k) {
+        for (int e = 0; e < mm; ++e) { const double v = Bm[lane * mmp + e]; t2 = fma(v, v, t2); }
+        last = Bm[lane * mmp + m];
+    }
+    const double smax = wave_max(lane < k ? t2 : 0.0);                   // eigenvalues of G = sigma(E)^2
+    const double cut = 2.220446049250313e-16 * (double)k * smax;
+    const bool keep = (lane < k) && (t2 > cut);
+    return wave_sum(keep ? (1.0 - last * last / t2) : 0.0);
+}
+
 // algorithms.py:285-296 given the NNLS solution st.x at lambda = x:
 //   log( (r^2/m) / ((m - trace(Dr G^+ Dr^T))/m)^2 ),  G = Dr^T Dr + c 11^T,  c = x * sum_{j in S} L_jj^2
 // (the scalar-broadcast quirk of algorithms.py:289-293), G^+ = SVD-truncated pseudo-inverse with
@@ -204,6 +302,19 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     double *cn2 = A + mm * k;                          // [mm] squared column norms
     double *wl = cn2 + mm;                             // [mm] last row of the accumulated rotations
     const double sc = sqrt(c);
+    if (k <= 32 && S.Dt && mm <= 4 * MET2_GCV_ROWS && k * (mm | 1) + k <= S.rcap) {
+#ifdef MET2_CYCSTATS
+        const unsigned long long cs0 = __builtin_readcyclecounter();
+#endif
+        int nsw;
+        const double tr = gcv_trace_small<NB>(S, sp, k, sc, lane, nsw);
+#ifdef MET2_CYCSTATS
+        stw.cyc[5] += __builtin_readcyclecounter() - cs0; stw.cyc[6] += 1; stw.cyc[7] += nsw; stw.cyc[4] += k;
+#endif
+        const double num = (1.0 / m) * rn2;
+        const double den = (1.0 / m) * ((double)m - tr);
+        return log(num / (den * den));
+    }
     for (int e = 0; e < mm; ++e) {
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
@@ -213,10 +324,6 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     }
     if (lane < mm) wl[lane] = (lane == m) ? 1.0 : 0.0;
     __builtin_amdgcn_wave_barrier();
-#ifdef MET2_CYCSTATS
-    const unsigned long long c1 = __builtin_readcyclecounter();
-    stw.cyc[5] += c1 - c0;
-#endif
     // Round-robin ("tournament") ordering: N = mm rounded up to even players, N-1 rounds of N/2 disjoint column
     // pairs; with mm odd the fixed player is a dummy and its pair is skipped.  Every pair gets LP lanes: the
     // lanes of a pair split the k rows, partial inner products meet through LP-wide xor shuffles, and the
@@ -280,14 +387,8 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
             __builtin_amdgcn_wave_barrier();
         }
         MET2_STAT(6, sweep + 1);
-#ifdef MET2_CYCSTATS
-        stw.cyc[7] += 1;
-#endif
         if (!rotated) break;
     }
-#ifdef MET2_CYCSTATS
-    stw.cyc[6] += __builtin_readcyclecounter() - c1;
-#endif
     double t2 = 0.0;
     for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; t2 = fma(v, v, t2); }
     const double smax = wave_max(lane < mm ? t2 : 0.0);                  // singular values of G = sigma(E)^2
