@@ -157,11 +157,14 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // of both columns (<= MET2_GCV_ROWS rows) in registers between the inner product and the rotation.
 // Returns trace(Dr G^+ Dr^T) = sum_{kept r} (1 - U[m][r]^2).
 #define MET2_GCV_ROWS 13                                      // ceil((n_te + 1) / 4) for n_te <= 51
+// column stride = 4 mod 32 doubles: the four lanes of a pair read consecutive rows, the 16 pairs of a round land
+// on banks 4 apart
+__device__ __forceinline__ int gcv_small_stride(int mm) { return ((mm + 27) / 32) * 32 + 4; }
 template <int NB>
 __device__ __forceinline__ double gcv_trace_small(const WaveShared &S, const int (&sp)[NB], int k, double sc, int lane, int &nsweep_done)
 {
     nsweep_done = 0;
-    const int m = S.m, mm = m + 1, mmp = mm | 1;
+    const int m = S.m, mm = m + 1, mmp = gcv_small_stride(mm);
     double *Bm = S.R;                                       // column r at Bm + r * mmp, rows 0..m
     double *cn2 = Bm + k * mmp;                             // [k] squared column norms
     {
@@ -302,7 +305,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     double *cn2 = A + mm * k;                          // [mm] squared column norms
     double *wl = cn2 + mm;                             // [mm] last row of the accumulated rotations
     const double sc = sqrt(c);
-    if (k <= 32 && S.Dt && mm <= 4 * MET2_GCV_ROWS && k * (mm | 1) + k <= S.rcap) {
+    if (k <= 32 && S.Dt && mm <= 4 * MET2_GCV_ROWS && k * gcv_small_stride(mm) + k <= S.rcap) {
 #ifdef MET2_CYCSTATS
         const unsigned long long cs0 = __builtin_readcyclecounter();
 #endif
