@@ -173,16 +173,33 @@ __device__ __forceinline__ void band_mul(const double (&bnd)[NB][5], const doubl
         out[b] = bnd[b][2] * v[b] + bnd[b][0] * m2[b] + bnd[b][1] * m1[b] + bnd[b][3] * p1[b] + bnd[b][4] * p2[b];
 }
 
-// Lawson-Hanson plane rotation (g1)
-__device__ __forceinline__ void givens(double a, double b, double &c, double &s, double &sig)
+// 1/sqrt(d) to fp64 accuracy from v_rsq_f64 and two Newton steps (d > 0, normal range)
+__device__ __forceinline__ double rsqrt_nr(double d)
 {
-    if (fabs(a) > fabs(b)) {
-        double xr = b / a, yr = sqrt(1.0 + xr * xr);
-        c = copysign(1.0 / yr, a); s = c * xr; sig = fabs(a) * yr;
-    } else if (b != 0.0) {
-        double xr = a / b, yr = sqrt(1.0 + xr * xr);
-        s = copysign(1.0 / yr, b); c = s * xr; sig = fabs(b) * yr;
-    } else { sig = 0.0; c = 0.0; s = 1.0; }
+    double r = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    double e = fma(-hd * r, r, 0.5);
+    r = fma(r, e, r);
+    e = fma(-hd * r, r, 0.5);
+    return fma(r, e, r);
+}
+
+// 1/d to fp64 accuracy from v_rcp_f64 and two Newton steps (d != 0, normal range)
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return fma(r, fma(-d, r, 1.0), r);
+}
+
+// Lawson-Hanson plane rotation (g1): c = a / sig, s = b / sig, sig = sqrt(a^2 + b^2) >= 0 (g1's two branches
+// reduce to this; the operands here are O(1), so the unscaled a^2 + b^2 neither overflows nor underflows).
+// rinv = 1 / sig comes out of the same rsq + Newton chain that replaces the sqrt and the two divisions.
+__device__ __forceinline__ void givens(double a, double b, double &c, double &s, double &sig, double &rinv)
+{
+    const double r2 = fma(a, a, b * b);
+    if (r2 > 0.0) { rinv = rsqrt_nr(r2); c = a * rinv; s = b * rinv; sig = r2 * rinv; }
+    else { sig = 0.0; c = 0.0; s = 1.0; rinv = INFINITY; }
 }
 
 // back substitution R z = y ; z position-indexed.
@@ -270,8 +287,8 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
                 rowj[b] = (pl >= j && pl < k) ? S.R[cbl[b] + j] : 0.0;
             }
             double a = bcastN<NB>(carry, j), bb = bcastN<NB>(rowj, j);
-            double c, s, sig;
-            givens(a, bb, c, s, sig);
+            double c, s, sig, sinv;
+            givens(a, bb, c, s, sig, sinv);
             double yj = bcastN<NB>(st.y, j);
             double ynew = c * ycar + s * yj;
             ycar = -s * ycar + c * yj;
@@ -283,7 +300,7 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
                 // new entry (j-1, pl-1): col_base(pl-1) = col_base(pl) - pl
                 if (pl > j && pl < k) S.R[cbl[b] - pl + j - 1] = nv;
                 if (pl == j) S.R[cbl[b] - pl + j - 1] = sig;
-                if (pl == j - 1) { st.y[b] = ynew; st.rinv[b] = 1.0 / sig; }
+                if (pl == j - 1) { st.y[b] = ynew; st.rinv[b] = sinv; }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -366,14 +383,14 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
     wave_sum2(rr, ry);
     const double rho2 = gtt - rr;
     if (!(rho2 > 1e-14 * gtt)) return false;                     // dependent column (noise floor of gtt - r.r)
-    const double rho = sqrt(rho2);
-    const double ynew = (bcastN<NB>(st.h, t) - ry) / rho;
-    if (!forced && !(ynew / rho > 0.0)) return false;            // ztest
+    const double rhoinv = rsqrt_nr(rho2), rho = rho2 * rhoinv;
+    const double ynew = (bcastN<NB>(st.h, t) - ry) * rhoinv;
+    if (!forced && !(ynew > 0.0)) return false;                  // ztest: the trial coefficient ynew / rho has ynew's sign
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
         if (pl < k) S.R[col_base(k) + pl] = r[b];
-        if (pl == k) { S.R[col_base(k) + k] = rho; st.rinv[b] = 1.0 / rho; st.y[b] = ynew; st.ord[b] = t; }
+        if (pl == k) { S.R[col_base(k) + k] = rho; st.rinv[b] = rhoinv; st.y[b] = ynew; st.ord[b] = t; }
         if (pl == t) st.pos[b] = k;
     }
     __builtin_amdgcn_wave_barrier();
@@ -557,25 +574,6 @@ __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 #pragma unroll
     for (int b = 0; b < NB; ++b) { st.x[b] = 0.0; st.y[b] = 0.0; st.rinv[b] = 0.0; st.ord[b] = 0; st.pos[b] = -1; st.P[b] = 0ull; }
     st.k = 0;
-}
-
-// 1/sqrt(d) to fp64 accuracy from v_rsq_f64 and two Newton steps (d > 0, normal range)
-__device__ __forceinline__ double rsqrt_nr(double d)
-{
-    double r = __builtin_amdgcn_rsq(d);
-    const double hd = 0.5 * d;
-    double e = fma(-hd * r, r, 0.5);
-    r = fma(r, e, r);
-    e = fma(-hd * r, r, 0.5);
-    return fma(r, e, r);
-}
-
-// 1/d to fp64 accuracy from v_rcp_f64 and two Newton steps (d != 0, normal range)
-__device__ __forceinline__ double rcp_nr(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(r, fma(-d, r, 1.0), r);
-    return fma(r, fma(-d, r, 1.0), r);
 }
 
 // Rebuild R, 1/diag and y = R^-T h_P for the CURRENT passive set and pivot order at a new lambda.
