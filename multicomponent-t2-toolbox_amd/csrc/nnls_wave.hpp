@@ -590,7 +590,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
     const int k = st.k, n = S.n;
     int cbl[NB], cbc[NB];
     unsigned jc[NB];
-    double g[NB], gbn[NB], gkn[NB];
+    double g[NB], gb0[NB], gk0[NB], gb1[NB], gk1[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
@@ -600,30 +600,88 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         const double hh = gatherN<NB>(st.h, st.ord[b]);
         g[b] = (pl < k) ? hh : 0.0;
     }
-    {
-        const int t = bcastN_i<NB>(st.ord, 0);
+    // rows of B and K for pivots p and p + 1 (clamped to the last pivot)
+    auto fetch = [&](int p, double (&vb)[NB], double (&vk)[NB]) {
+        const int t = bcastN_i<NB>(st.ord, min(p, k - 1));
         const double *Brow = S.B + t * S.bstride, *Krow = S.K + t * n;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { gbn[b] = Brow[jc[b]]; gkn[b] = Krow[jc[b]]; }
-    }
+        for (int b = 0; b < NB; ++b) { vb[b] = Brow[jc[b]]; vk[b] = Krow[jc[b]]; }
+    };
+    // finish a row: a holds A[i][c] - sum_{j<i} R[j][i] R[j][c]; scale, store column entries, one elimination step for y
+    auto finish = [&](int i, double (&a)[NB], double gdiag, double (&r)[NB]) -> bool {
+        const double d = bcastN<NB>(a, i);
+        const double rinv = rsqrt_nr(d);
+        const double yi = bcastN<NB>(g, i) * rinv;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            r[b] = a[b] * rinv;                                         // lane i: d * rinv = R[i][i]
+            if (pl >= i && pl < k) S.R[cbl[b] + i] = r[b];
+            g[b] = (pl > i) ? fma(-r[b], yi, g[b]) : g[b];
+        }
+        return !(d > 1e-14 * gdiag);
+    };
+    fetch(0, gb0, gk0);
+    fetch(1, gb1, gk1);
     int cbi = 0;                                                        // col_base(i)
     bool bad = false;
-    for (int i = 0; i < k; ++i) {
-        double gb[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) gb[b] = fma(lam, gkn[b], gbn[b]);                                        // G[.][ord_i], bin-indexed
+    int i = 0;
+    // two rows per step: rows i and i + 1 share the reads of the rows above them, and row i + 1 takes row i's
+    // contribution from registers, so the pair costs one LDS round trip instead of two
+    for (; i + 1 < k; i += 2) {
+        double a[NB], a2[NB], c[NB], c2[NB];
         {
-            const int t = bcastN_i<NB>(st.ord, min(i + 1, k - 1));
-            const double *Brow = S.B + t * S.bstride, *Krow = S.K + t * n;
+            double t0[NB], t1[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { gbn[b] = Brow[jc[b]]; gkn[b] = Krow[jc[b]]; }
+            for (int b = 0; b < NB; ++b) { t0[b] = fma(lam, gk0[b], gb0[b]); t1[b] = fma(lam, gk1[b], gb1[b]); }   // G[.][ord_i], G[.][ord_i+1]
+            fetch(i + 2, gb0, gk0);
+            fetch(i + 3, gb1, gk1);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); a2[b] = 0.0; c2[b] = 0.0; }
         }
-        double a[NB], a2[NB];
+        const double gd0 = bcastN<NB>(a, i), gd1 = bcastN<NB>(c, i + 1);
+        const double *ci = S.R + cbi, *cj = ci + i + 1;                 // columns i and i + 1
+        int j = 0;
+#pragma clang loop unroll(disable)
+        for (; j + 4 <= i; j += 4) {
+            const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
+            const double u0 = cj[j], u1 = cj[j + 1], u2 = cj[j + 2], u3 = cj[j + 3];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(gb, st.ord[b]); a2[b] = 0.0; }                      // A[i][c]
-        const double gdiag = bcastN<NB>(a, i);
-        // a[c] -= sum_{j<i} R[j][i] R[j][c]: column i (one address for the whole wave) and the lane's own column c,
-        // four consecutive rows per step
+            for (int b = 0; b < NB; ++b) {
+                const double *cc = S.R + cbc[b] + j;
+                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
+                c[b] = fma(-u0, q0, c[b]); c2[b] = fma(-u1, q1, c2[b]);
+                a[b] = fma(-s2, q2, a[b]); a2[b] = fma(-s3, q3, a2[b]);
+                c[b] = fma(-u2, q2, c[b]); c2[b] = fma(-u3, q3, c2[b]);
+            }
+        }
+        for (; j < i; ++j) {
+            const double s0 = ci[j], u0 = cj[j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const double q0 = S.R[cbc[b] + j]; a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]); }
+        }
+        double r[NB], r1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { a[b] += a2[b]; c[b] += c2[b]; }
+        bad = finish(i, a, gd0, r) || bad;
+        const double sr = bcastN<NB>(r, i + 1);                         // R[i][i+1]
+#pragma unroll
+        for (int b = 0; b < NB; ++b) c[b] = fma(-sr, r[b], c[b]);
+        bad = finish(i + 1, c, gd1, r1) || bad;
+        __builtin_amdgcn_wave_barrier();
+        cbi += 2 * i + 3;                                               // col_base(i + 2) - col_base(i)
+    }
+    if (i < k) {                                                        // odd k: the last row on its own
+        double a[NB], a2[NB];
+        {
+            double t0[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) t0[b] = fma(lam, gk0[b], gb0[b]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); a2[b] = 0.0; }
+        }
+        const double gd0 = bcastN<NB>(a, i);
         const double *ci = S.R + cbi;
         int j = 0;
 #pragma clang loop unroll(disable)
@@ -642,21 +700,11 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
 #pragma unroll
             for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + j], a[b]);
         }
+        double r[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) a[b] += a2[b];
-        const double d = bcastN<NB>(a, i);
-        bad = bad || !(d > 1e-14 * gdiag);
-        const double rinv = rsqrt_nr(d);
-        const double yi = bcastN<NB>(g, i) * rinv;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int pl = lane + 64 * b;
-            const double r = a[b] * rinv;                               // lane i: d * rinv = R[i][i]
-            if (pl >= i && pl < k) S.R[cbl[b] + i] = r;
-            g[b] = (pl > i) ? fma(-r, yi, g[b]) : g[b];
-        }
+        bad = finish(i, a, gd0, r) || bad;
         __builtin_amdgcn_wave_barrier();
-        cbi += i + 1;
     }
     if (bad) return false;
     // lane p: 1 / R[p][p] and y_p = g_p / R[p][p] (g_p is final once rows < p are eliminated)
@@ -664,7 +712,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
         const double dg = (pl < k) ? S.R[cbl[b] + pl] : 1.0;
-        const double ri = 1.0 / dg;
+        const double ri = rcp_nr(dg);
         st.rinv[b] = (pl < k) ? ri : st.rinv[b];
         st.y[b] = (pl < k) ? g[b] * ri : st.y[b];
     }
