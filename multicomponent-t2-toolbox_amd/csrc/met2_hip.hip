@@ -408,7 +408,7 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int d = 0; d < 5; ++d) { bd.kb[b][d] = kband[d * 128 + lane + 64 * b]; bd.lb[b][d] = lband[d * 128 + lane + 64 * b]; }
+        for (int d = 0; d < 5; ++d) bd.lb[b][d] = lband[d * 128 + lane + 64 * b];
 }
 
 // METHOD: met2_method, or 10 + method for the objective-grid diagnostic.  NB: T2 bins per lane.
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
     int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.Dt = nullptr; S.dtstride = m;
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.dtstride = m;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -636,14 +636,14 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     double *sR = sR0 + (size_t)wave * A.wave_doubles;
     int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.Dt = nullptr; S.dtstride = m;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.dtstride = m;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int d = 0; d < 5; ++d) { bd.kb[b][d] = 0.0; bd.lb[b][d] = 0.0; }
+        for (int d = 0; d < 5; ++d) bd.lb[b][d] = 0.0;
     const int tile_vox = A.waves * VPW;
     const int64_t ntiles = (A.nvox + tile_vox - 1) / tile_vox;
     for (int64_t round = 0; round <= ntiles; ++round) {

@@ -53,6 +53,7 @@ struct WaveShared {
     const double *B;    // [n][bstride]
     const double *K;    // [n][n] dense L^T L in global memory (fit kernel only)
     const double *Dt;   // [n][dtstride] transposed D in global memory, or NULL (then columns of D are read)
+    const double *kband; // [5][128] diagonals of K in global memory: kband[d*128 + j] = K[j][j+d-2] (loaded where the stencil is applied)
     int dtstride;
     const double *D;    // [m][dstride]
     double *R;          // this wave's LDS region
@@ -60,10 +61,11 @@ struct WaveShared {
     int rcap;           // doubles available at R
 };
 
-// K = L^T L and L itself as 5 diagonals per owned bin: kb[b][d] = K[j][j+d-2], lb[b][d] = L[j][j+d-2]
+// L as 5 diagonals per owned bin: lb[b][d] = L[j][j+d-2].  (K = L^T L is not held in registers: its rows come from the
+// dense copy S.K, its diagonals for the 5-point stencil of the dual from S.kband -- 10 VGPRs less to carry through
+// the whole voxel loop.)
 template <int NB>
 struct Band {
-    double kb[NB][5];
     double lb[NB][5];
 };
 
@@ -332,7 +334,7 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
     for (int b = 0; b < NB; ++b) {
         const int j = lane + 64 * b;
         gb[b] = (j < S.n) ? S.B[t * S.bstride + j] : 0.0;
-        gb[b] = fma(lam, band_pick(bd.kb[b], t - j), gb[b]);            // G[j][t]
+        if (lam != 0.0) gb[b] = fma(lam, (j < S.n) ? S.K[t * S.n + j] : 0.0, gb[b]);       // G[j][t] (K is symmetric: row t)
     }
     const double gtt = bcastN<NB>(gb, t);
     double g[NB], rv[NB];
@@ -403,6 +405,13 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
 template <int NB>
 __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double lam, int lane, double (&w)[NB])
 {
+    double kbl[NB][5];                                       // this lane's 5 diagonals of K, in flight during the B loop
+    if (lam != 0.0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) kbl[b][d] = S.kband[d * 128 + lane + 64 * b];
+    }
     // B x over the passive set, four rows of B in flight per step (the rows come from L2: issued back to back they
     // overlap their latency, one at a time each step would wait for its own load)
     double acc[NB], acc2[NB], xp[NB];
@@ -436,7 +445,7 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
     double kx[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) kx[b] = 0.0;
-    if (lam != 0.0) band_mul<NB>(bd.kb, st.x, lane, kx);
+    if (lam != 0.0) band_mul<NB>(kbl, st.x, lane, kx);
 #pragma unroll
     for (int b = 0; b < NB; ++b) w[b] = (lane + 64 * b < S.n) ? fma(-lam, kx[b], st.h[b] - acc[b]) : 0.0;
 }
@@ -643,17 +652,15 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         const double *ci = S.R + cbi, *cj = ci + i + 1;                 // columns i and i + 1
         int j = 0;
 #pragma clang loop unroll(disable)
-        for (; j + 4 <= i; j += 4) {
-            const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
-            const double u0 = cj[j], u1 = cj[j + 1], u2 = cj[j + 2], u3 = cj[j + 3];
+        for (; j + 2 <= i; j += 2) {                                    // two rows above per step (one ds_read2 per column)
+            const double s0 = ci[j], s1 = ci[j + 1];
+            const double u0 = cj[j], u1 = cj[j + 1];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const double *cc = S.R + cbc[b] + j;
-                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                const double q0 = cc[0], q1 = cc[1];
                 a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
                 c[b] = fma(-u0, q0, c[b]); c2[b] = fma(-u1, q1, c2[b]);
-                a[b] = fma(-s2, q2, a[b]); a2[b] = fma(-s3, q3, a2[b]);
-                c[b] = fma(-u2, q2, c[b]); c2[b] = fma(-u3, q3, c2[b]);
             }
         }
         for (; j < i; ++j) {
