@@ -26,7 +26,7 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
     const double bl = beta * lam;
     int cbl[NB], cbc[NB];
     unsigned jc[NB];
-    double diag[NB], gbn[NB], gkn[NB];
+    double diag[NB], gb0[NB], gk0[NB], gb1[NB], gk1[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
@@ -34,51 +34,81 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
         cbc[b] = col_base(min(pl, n - 1));
         jc[b] = (unsigned)min(pl, n - 1);
         diag[b] = 1.0;
-        gbn[b] = S.B[jc[b]]; gkn[b] = S.K[jc[b]];
     }
-    int cbj = 0;                                                        // col_base(j)
-    for (int j = 0; j < n; ++j) {
-        double a[NB], a2[NB];
+    auto fetch = [&](int j, double (&vb)[NB], double (&vk)[NB]) {
+        const int jj = min(j, n - 1);
+        const double *Brow = S.B + jj * S.bstride, *Krow = S.K + jj * n;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { a[b] = fma(bl, gkn[b], beta * gbn[b]); a2[b] = 0.0; }                  // A[j][c]
-        {
-            const int jn = min(j + 1, n - 1);
-            const double *Brow = S.B + jn * S.bstride, *Krow = S.K + jn * n;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { gbn[b] = Brow[jc[b]]; gkn[b] = Krow[jc[b]]; }
-        }
-        const double *cj = S.R + cbj;
-        int k = 0;
-#pragma clang loop unroll(disable)
-        for (; k + 4 <= j; k += 4) {
-            const double s0 = cj[k], s1 = cj[k + 1], s2 = cj[k + 2], s3 = cj[k + 3];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const double *cc = S.R + cbc[b] + k;
-                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
-                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
-                a[b] = fma(-s2, q2, a[b]); a2[b] = fma(-s3, q3, a2[b]);
-            }
-        }
-        for (; k < j; ++k) {
-            const double s0 = cj[k];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + k], a[b]);
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) a[b] += a2[b];
+        for (int b = 0; b < NB; ++b) { vb[b] = Brow[jc[b]]; vk[b] = Krow[jc[b]]; }
+    };
+    // scale a finished row, store its column entries; false when the pivot is not positive
+    auto finish = [&](int j, double (&a)[NB], double (&u)[NB]) -> bool {
         const double d = bcastN<NB>(a, j);
-        if (!(d > 0.0)) return false;
         const double rinv = rsqrt_nr(d);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int c = lane + 64 * b;
-            const double u = a[b] * rinv;                               // lane j: d * rinv = U[j][j]
-            if (c >= j && c < n) S.R[cbl[b] + j] = u;
-            if (c == j) diag[b] = u;
+            u[b] = a[b] * rinv;                                         // lane j: d * rinv = U[j][j]
+            if (c >= j && c < n) S.R[cbl[b] + j] = u[b];
+            if (c == j) diag[b] = u[b];
         }
+        return d > 0.0;
+    };
+    fetch(0, gb0, gk0);
+    fetch(1, gb1, gk1);
+    int cbj = 0;                                                        // col_base(j)
+    int j = 0;
+    for (; j + 1 < n; j += 2) {                                         // rows j and j + 1 together, as in refactor()
+        double a[NB], a2[NB], c[NB], c2[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            a[b] = fma(bl, gk0[b], beta * gb0[b]); c[b] = fma(bl, gk1[b], beta * gb1[b]);                     // A[j][.], A[j+1][.]
+            a2[b] = 0.0; c2[b] = 0.0;
+        }
+        fetch(j + 2, gb0, gk0);
+        fetch(j + 3, gb1, gk1);
+        const double *cj = S.R + cbj, *cj1 = cj + j + 1;                // columns j and j + 1
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 2 <= j; k += 2) {
+            const double s0 = cj[k], s1 = cj[k + 1];
+            const double u0 = cj1[k], u1 = cj1[k + 1];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double *cc = S.R + cbc[b] + k;
+                const double q0 = cc[0], q1 = cc[1];
+                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
+                c[b] = fma(-u0, q0, c[b]); c2[b] = fma(-u1, q1, c2[b]);
+            }
+        }
+        for (; k < j; ++k) {
+            const double s0 = cj[k], u0 = cj1[k];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const double q0 = S.R[cbc[b] + k]; a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]); }
+        }
+        double u[NB], w[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { a[b] += a2[b]; c[b] += c2[b]; }
+        if (!finish(j, a, u)) return false;
+        const double su = bcastN<NB>(u, j + 1);                         // U[j][j+1]
+#pragma unroll
+        for (int b = 0; b < NB; ++b) c[b] = fma(-su, u[b], c[b]);
+        if (!finish(j + 1, c, w)) return false;
         __builtin_amdgcn_wave_barrier();
-        cbj += j + 1;
+        cbj += 2 * j + 3;
+    }
+    if (j < n) {                                                        // odd n: the last row on its own
+        double a[NB], u[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a[b] = fma(bl, gk0[b], beta * gb0[b]);
+        const double *cj = S.R + cbj;
+        for (int k = 0; k < j; ++k) {
+            const double s0 = cj[k];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + k], a[b]);
+        }
+        if (!finish(j, a, u)) return false;
+        __builtin_amdgcn_wave_barrier();
     }
     double dp = 1.0;
 #pragma unroll
