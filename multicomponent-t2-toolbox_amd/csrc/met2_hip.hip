@@ -444,9 +444,18 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
     const int nchunks = A.sb.chunk_start[A.nfa];
     int loaded_fa = -1;
     for (int round = 0; round <= nchunks; ++round) {      // the queue hands out each chunk once
-        if (threadIdx.x == 0) { sI[0] = atomicAdd(A.sb.queue, 1); sI[1] = 0; }
-        __syncthreads();
-        const int c = sI[0];
+        // unstaged: every WAVE pulls its own (small) chunk from the global queue -- no workgroup barrier anywhere, so a
+        // wave never idles while its neighbours finish their voxels.  Staged: the workgroup shares a chunk (the staged
+        // D and B belong to its flip angle) and hands out its voxels through an LDS counter.
+        int c = 0;
+        if (STAGE) {
+            if (threadIdx.x == 0) { sI[0] = atomicAdd(A.sb.queue, 1); sI[1] = 0; }
+            __syncthreads();
+            c = sI[0];
+        } else {
+            if (lane == 0) c = atomicAdd(A.sb.queue, 1);
+            c = __builtin_amdgcn_readfirstlane(c);
+        }
         MET2_STAT(5, round);
         if (c >= nchunks) break;
         int lo = 0, hi = A.nfa;                       // largest fa with chunk_start[fa] <= c
@@ -465,9 +474,12 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
             }
         } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
         for (int taken = 0; taken <= cnt; ++taken) {
-            int slot = 0;
-            if (lane == 0) slot = atomicAdd(&sI[1], 1);
-            slot = __builtin_amdgcn_readfirstlane(slot);
+            int slot = taken;
+            if (STAGE) {
+                slot = 0;
+                if (lane == 0) slot = atomicAdd(&sI[1], 1);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+            }
             MET2_STAT(4, taken);
             if (slot >= cnt) break;
             const int64_t v = A.sb.perm[first + slot];
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
                 if (A.status) A.status[v] = stat;
             }
         }
-        __syncthreads();
+        if (STAGE) __syncthreads();
     }
 }
 
@@ -1529,7 +1541,12 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 8), s));
     const int nb = (int)((nvox + 255) / 256);
-    const int chunk = 128;
+    // work-queue granularity: 128 voxels per workgroup when D/B are staged per flip angle, otherwise every wave pulls
+    // single voxels (measured on configs[1]: 1 / 2 / 4 / 8 / 16 voxels per pull -> 5.37 / 5.32 / 5.22 / 5.04 / 4.71 M voxels/s;
+    // one atomic per voxel is ~5 M/s on the queue word)
+    int chunk = 128;
+    if (!g.stage) chunk = 1;
+    if (const char *e = getenv("MET2_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 1024) chunk = c; }
     const bool dbg = getenv("MET2_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit: nvox=%lld grid=%d block=%d lds=%d\n", (long long)nvox, g.grid, g.block, g.lds); fflush(stderr); }
     hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, fa_index, mask, 1, sb, status);
