@@ -1541,11 +1541,13 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 8), s));
     const int nb = (int)((nvox + 255) / 256);
-    // work-queue granularity: 128 voxels per workgroup when D/B are staged per flip angle, otherwise every wave pulls
-    // single voxels (measured on configs[1]: 1 / 2 / 4 / 8 / 16 voxels per pull -> 5.37 / 5.32 / 5.22 / 5.04 / 4.71 M voxels/s;
-    // one atomic per voxel is ~5 M/s on the queue word)
+    // work-queue granularity: 128 voxels per workgroup when D/B are staged per flip angle; otherwise every wave pulls
+    // its own voxels -- one at a time for the methods that spend ~1 ms per voxel (X2/L2 on configs[1]: 1 / 2 / 4 / 8 / 16
+    // voxels per pull -> 5.37 / 5.32 / 5.22 / 5.04 / 4.71 M voxels/s; HBM writes 1.01 / 0.93 / 0.88 / 0.89 GB because the
+    // 8-byte per-voxel outputs of neighbouring voxels then leave from different XCDs), eight at a time for NNLS and
+    // T2SPARC, where one atomic per voxel on the queue word would cap the kernel at 23 M voxels/s (8 -> 82 M)
     int chunk = 128;
-    if (!g.stage) chunk = 1;
+    if (!g.stage) chunk = ((objgrid ? method - MET2_OBJECTIVE_GRID : method) <= MET2_T2SPARC) ? 8 : 1;
     if (const char *e = getenv("MET2_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 1024) chunk = c; }
     const bool dbg = getenv("MET2_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit: nvox=%lld grid=%d block=%d lds=%d\n", (long long)nvox, g.grid, g.block, g.lds); fflush(stderr); }
