@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
 // ------------------------------------------------------------------------------------------
 struct FaArgs {
     int n, m, nfa, np, kmax, waves, wave_doubles;
-    const double *Dfa, *Bfa;
+    const double *Dfa, *Bfa, *Dtfa;
     const double *Kd;         // [n][n], only multiplied by lambda = 0 here (the refactorisation reads its rows)
     const double *data;
     const uint8_t *mask;
@@ -635,13 +635,12 @@ struct FaArgs {
     int64_t nvox;
 };
 
-template <int VPW, int NB, int WAVES>
+template <int VPW, int NB, int WAVES, bool STAGE>
 __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, np = A.np;
-    constexpr bool STAGE = (NB == 1);
     double *sB = smem;
     double *sD = sB + (STAGE ? n * np : 0);
     double *sR0 = sD + (STAGE ? m * np : 0);
@@ -656,14 +655,25 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int d = 0; d < 5; ++d) bd.lb[b][d] = 0.0;
-    const int tile_vox = A.waves * VPW;
+    // staged: a workgroup shares a tile of waves x VPW voxels and the LDS copies of each flip angle's D and B (two
+    // barriers per flip angle).  Unstaged: every wave pulls its own VPW voxels and walks the flip angles alone, reading
+    // D, D^T and B through L1/L2 -- no barrier, so no wave waits for the slowest solve of the tile (the staged kernel
+    // spent 48 % of its wave time in those barriers).
+    const int tile_vox = (STAGE ? A.waves : 1) * VPW;
     const int64_t ntiles = (A.nvox + tile_vox - 1) / tile_vox;
     for (int64_t round = 0; round <= ntiles; ++round) {
-        if (threadIdx.x == 0) sI[0] = atomicAdd(A.queue, 1);
-        __syncthreads();
-        const int64_t tile = sI[0];
+        int64_t tile = 0;
+        if (STAGE) {
+            if (threadIdx.x == 0) sI[0] = atomicAdd(A.queue, 1);
+            __syncthreads();
+            tile = sI[0];
+        } else {
+            int t32 = 0;
+            if (lane == 0) t32 = atomicAdd(A.queue, 1);
+            tile = __builtin_amdgcn_readfirstlane(t32);
+        }
         if (tile >= ntiles) break;
-        const int64_t v0 = tile * tile_vox + (int64_t)wave * VPW;
+        const int64_t v0 = tile * tile_vox + (STAGE ? (int64_t)wave * VPW : 0);
         double b[VPW], best_r[VPW], best_km[VPW];
         int best_fa[VPW];
         bool act[VPW];
@@ -689,15 +699,35 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             const double *Bf = A.Bfa + (size_t)fa * n * n;
             const double *Df = A.Dfa + (size_t)fa * m * n;
             if (STAGE) {
+#ifdef MET2_CYCSTATS
+                const unsigned long long cs0 = __builtin_readcyclecounter();
+#endif
                 __syncthreads();
+#ifdef MET2_CYCSTATS
+                const unsigned long long cs1 = __builtin_readcyclecounter();
+#endif
                 for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
                 for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
                 __syncthreads();
-            } else { S.B = Bf; S.D = Df; }
+#ifdef MET2_CYCSTATS
+                st[0].cyc[5] += cs1 - cs0; st[0].cyc[6] += __builtin_readcyclecounter() - cs1;
+#endif
+            } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
+#ifdef MET2_CYCSTATS
+            const unsigned long long cv0 = __builtin_readcyclecounter();
+#endif
+            if (!STAGE) {                      // rows of D come from L2: load each once for all the wave's voxels
+                double hh[VPW][NB];
+                project_multi<NB, VPW>(S, b, lane, hh);
+#pragma unroll
+                for (int vv = 0; vv < VPW; ++vv)
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) st[vv].h[bb] = hh[vv][bb];
+            }
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
                 if (!act[vv]) continue;
-                project<NB>(S, b[vv], lane, st[vv].h);
+                if (STAGE) project<NB>(S, b[vv], lane, st[vv].h);
                 nnls_solve_warm<NB>(S, bd, st[vv], 0.0, false, lane);
                 const double rn = sqrt(sse_of<NB>(S, st[vv], b[vv], lane));
                 if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
@@ -709,7 +739,14 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
                     best_km[vv] = wave_sum(t);
                 }
             }
+#ifdef MET2_CYCSTATS
+            st[0].cyc[0] += __builtin_readcyclecounter() - cv0;
+#endif
         }
+#ifdef MET2_CYCSTATS
+#pragma unroll
+        for (int vv = 0; vv < VPW; ++vv) MET2_CYC_FLUSH(st[vv]);
+#endif
 #pragma unroll
         for (int vv = 0; vv < VPW; ++vv) {
             const int64_t v = v0 + vv;
@@ -719,7 +756,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             }
             if (v < A.nvox && A.resid && !act[vv]) for (int f = lane; f < A.nfa; f += 64) A.resid[(size_t)v * A.nfa + f] = 0.0;
         }
-        __syncthreads();
+        if (STAGE) __syncthreads();
     }
 }
 
@@ -1633,9 +1670,12 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     hipStream_t s = (hipStream_t)stream;
     LaunchGeom g;
     // plain NNLS stops at min(n_t2, n_te) passive bins (Lawson-Hanson's k >= rows test), so the factor needs that
-    // capacity only: 4 KB per wave at nTE = 32 instead of 14.6 KB, and 16 waves share a CU with the staged D and B
+    // capacity only: 4 KB per wave at nTE = 32 instead of 14.6 KB.  Default: unstaged (every wave walks the flip angles
+    // on its own, 16 waves per CU); MET2_FA_STAGE=1 selects the tile kernel with D and B staged in LDS (nT2 <= 64).
     const int kcap = p->n_te < p->n_t2 ? p->n_te : 0;
-    int rc = fit_geometry(p, MET2_NNLS, g, false, kcap);
+    bool fa_stage = false;
+    if (const char *e = getenv("MET2_FA_STAGE")) fa_stage = atoi(e) != 0 && p->n_t2 <= 64;
+    int rc = fit_geometry(p, MET2_NNLS, g, !fa_stage, kcap);
     if (rc) return rc;
     const int fa_waves = g.waves >= 16 ? 16 : (g.waves >= 8 ? 8 : g.waves);
     if (g.waves != fa_waves) {
@@ -1646,19 +1686,29 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
     A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
-    A.Dfa = p->dD; A.Bfa = p->dB; A.Kd = p->dKd; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Kd = p->dKd; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
     HIPCHK(hipEventRecord(p->ev0, s));
-#define MET2_FA_LAUNCH(VPW, NB, WAVES)                                                                                   \
+#define MET2_FA_LAUNCH(VPW, NB, WAVES, STG)                                                                              \
     do {                                                                                                                \
-        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
-        hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES>), dim3(g.grid), dim3(g.block), g.lds, s, A);                       \
+        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
+        hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES, STG>), dim3(g.grid), dim3(g.block), g.lds, s, A);                  \
     } while (0)
-    if (g.nb == 1) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16); else MET2_FA_LAUNCH(4, 1, 8); }
-    else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16); else MET2_FA_LAUNCH(2, 2, 8); }
+    if (g.nb == 1) {
+        if (g.stage) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16, true); else MET2_FA_LAUNCH(4, 1, 8, true); }
+        else         { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16, false); else MET2_FA_LAUNCH(4, 1, 8, false); }
+    } else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16, false); else MET2_FA_LAUNCH(2, 2, 8, false); }
 #undef MET2_FA_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev1, s));
+#ifdef MET2_CYCSTATS
+    if (getenv("MET2_DEBUG")) {
+        HIPCHK(hipStreamSynchronize(s));
+        unsigned long long cy[8];
+        HIPCHK(hipMemcpyFromSymbol(cy, HIP_SYMBOL(met2::g_cyc), sizeof(cy)));
+        fprintf(stderr, "[met2] fa wave cycles: solves=%llu barrier-wait=%llu staging=%llu | refactor=%llu inner=%llu dual=%llu append=%llu\n", cy[0], cy[5], cy[6], cy[1], cy[2], cy[3], cy[4]);
+    }
+#endif
     p->timed = true;
     return MET2_OK;
 }

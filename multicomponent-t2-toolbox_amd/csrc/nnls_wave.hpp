@@ -836,6 +836,41 @@ __device__ __forceinline__ void project(const WaveShared &S, double bvec, int la
     for (int b = 0; b < NB; ++b) h[b] = (lane + 64 * b < S.n) ? h[b] : 0.0;
 }
 
+// h_v = D^T b_v for V voxels at once: every row of D is loaded once and used V times (eight rows in flight)
+template <int NB, int V>
+__device__ __forceinline__ void project_multi(const WaveShared &S, const double (&bvec)[V], int lane, double (&h)[V][NB])
+{
+    unsigned jc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) jc[b] = (unsigned)min(lane + 64 * b, S.n - 1);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) h[v][b] = 0.0;
+#pragma clang loop unroll(disable)
+    for (int e = 0; e < S.m; e += 8) {
+        double dv[8][NB];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double *Drow = S.D + min(e + q, S.m - 1) * S.dstride;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) dv[q][b] = Drow[jc[b]];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double be = (e + q < S.m) ? bcast(bvec[v], min(e + q, S.m - 1)) : 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) h[v][b] = fma(dv[q][b], be, h[v][b]);
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) h[v][b] = (lane + 64 * b < S.n) ? h[v][b] : 0.0;
+}
+
 // ||L x||^2 for the bin-indexed x (L as 5 diagonals)
 template <int NB>
 __device__ __forceinline__ double seminorm2(const Band<NB> &bd, const double (&x)[NB], int n, int lane)
