@@ -100,16 +100,20 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     vol_shape = data.shape[:-1]
     nt = data.shape[-1]
     mask = np.asarray(mask).reshape(vol_shape)
-    d2 = data
+    dev = plan.device if plan is not None else torch.device("cuda", device)
+    # the driver's preparation on the device (the volume goes up once; numpy would spend longer on these two passes
+    # than the GPU on the whole fit)
+    dd = torch.as_tensor(data, device=dev)
+    mk = torch.as_tensor(mask, device=dev)
     if not prepared:
-        d2 = data * mask[..., None]                   # the mask VALUE multiplies (motor:180-182)
-        d2 = np.where(d2 < 0.0, 0.0, d2)
+        dd = dd * mk.to(torch.float64).unsqueeze(-1)                # the mask VALUE multiplies (motor:180-182)
+        dd = torch.where(dd < 0.0, torch.zeros((), dtype=torch.float64, device=dev), dd)      # motor:279
         if denoise == "NESMA":
             if len(vol_shape) != 3:
                 raise ValueError("NESMA needs data [nx,ny,nz,nt]")
-            d2 = nesma_filter(d2, mask, device=device)
-    d2 = d2.reshape(-1, nt)
-    m1 = (mask.reshape(-1) > 0)
+            dd = nesma_filter(dd, mk)
+    dd = dd.reshape(-1, nt).contiguous()
+    mm = (mk.reshape(-1) > 0)
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
     Npc = 96 if reg_method == "T2SPARC" else 60
@@ -124,9 +128,6 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
         plan = Met2Plan(nt, Npc, alpha_values.shape[0], device=device, myelin_T2=myelin_T2)
         plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
         plan.set_penalty("InvT2" if reg_method == "T2SPARC" else reg_matrix, T2s)   # run_real_data_script.py:91-93
-    dev = plan.device
-    dd = torch.as_tensor(d2, device=dev)
-    mm = torch.as_tensor(m1, device=dev)
     if spline:
         plan_lr = Met2Plan(nt, Npc, 15, device=device)
         plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_values_spline, TR)
@@ -141,7 +142,7 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
            "Est_Signal": out["sig"].cpu().numpy().reshape(vol_shape + (nt,)),
            "reg_param": out["reg"].cpu().numpy().reshape(vol_shape),
            "FA_index": fa.cpu().numpy().reshape(vol_shape)}
-    fitted_fa = (m1 & (d2.sum(axis=1) > 0)).reshape(vol_shape)
+    fitted_fa = (mm & (dd.sum(dim=1) > 0)).cpu().numpy().reshape(vol_shape)
     res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
     maps = out["maps"].cpu().numpy()
     for i, name in enumerate(MAP_NAMES):
