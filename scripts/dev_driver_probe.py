@@ -1,0 +1,21 @@
+"""Wall time of the array-level driver (recon_met2_arrays: H2D, preparation, FA estimation, fit, metrics, D2H) on a
+configs[1]-sized volume, for the spline (CLI default) and brute-force FA methods."""
+import importlib, json, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+motor = importlib.import_module("multicomponent-t2-toolbox_amd.motor")
+synth = importlib.import_module("multicomponent-t2-toolbox_amd.synth")
+dims = tuple(int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "128,128,64").split(","))
+nvox = int(np.prod(dims))
+alphas = np.linspace(90.0, 180.0, 91)
+data, _, _ = synth.make_voxels(nvox, nte=32, seed=9, fa_values=alphas, device="cuda")
+data = data.cpu().numpy().reshape(dims + (32,))
+mask = np.ones(dims, dtype=np.int64)
+TE = 10.0 * np.arange(1, 33)
+for fa_method in ("spline", "brute-force"):
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = motor.recon_met2_arrays(data, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"driver": "recon_met2_arrays", "dims": dims, "FA_method": fa_method, "seconds": dt, "voxels_per_s": nvox / dt,
+                      "MWF_mean": float(res["MWF"].mean())}))
