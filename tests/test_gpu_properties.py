@@ -198,3 +198,37 @@ def test_edge_cases(pkg):
     p96.build_dictionary_epg(T96, 1000.0 * np.ones(96), 10.0, np.array([150.0]), 3000.0).set_penalty("InvT2", T96)
     o96 = p96.fit("T2SPARC", data)
     assert (o96["reg"] == 1.8).all() and (o96["fsol"] >= 0).all() and torch.isfinite(o96["fsol"]).all()
+
+
+@pytest.mark.parametrize("nte,nt2", [(8, 12), (16, 20), (24, 40), (32, 64), (32, 65), (40, 96), (63, 128), (30, 33)])
+def test_odd_shapes_vs_oracle(pkg, nte, nt2):
+    # shapes other than the two the reference ships: lane-count edges (nT2 = 64 / 65), echo counts that are no multiple
+    # of the load batches, nT2 > 2 nTE and nT2 close to nTE -- X2/L2, plain NNLS, the FA walk and the spline path's
+    # residuals all through the same kernels
+    import torch
+    from oracle import oracle
+    oracle.build()
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    alphas = np.linspace(120.0, 180.0, 7)
+    plan = pkg.Met2Plan(nte, nt2, 7)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, alphas, 3000.0).set_penalty("L2", T2s)
+    nvox = 300
+    data, fa, _ = synth.make_voxels(nvox, nte=nte, seed=1000 + nte * 131 + nt2, fa_values=alphas, device="cuda")
+    D = np.ascontiguousarray(np.transpose(plan.get_dictionary(), (2, 0, 1)))
+    L = oracle.penalty(nt2, "L2", T2s)
+    d = data.cpu().numpy(); f = fa.cpu().numpy(); ones = np.ones(nvox)
+    for meth in ("NNLS", "X2"):
+        out = plan.fit(meth, data, fa_index=fa, want_lambda=True)
+        fs, sg, rg, so = oracle.fit_batch(meth, D, L, d, f, ones, nthreads=8)
+        got = out["fsol"].cpu().numpy(); gs = out["sig"].cpu().numpy()
+        e = np.max(np.abs(got - fs), axis=1) / np.max(np.abs(fs), axis=1)
+        es = np.max(np.abs(gs - sg), axis=1) / np.max(np.abs(sg), axis=1)
+        # the fitted signal is unique even where a near-degenerate dictionary (tiny nTE) leaves the spectrum loose
+        assert np.mean(es < 1e-5) >= 0.99, (meth, nte, nt2, es.max())
+        assert np.mean(e < 1e-5) >= (0.97 if nte >= 16 else 0.8), (meth, nte, nt2, np.mean(e < 1e-5), e.max())
+        assert (out["status"].cpu().numpy() & 1).all()
+    idx, km, sse, ff, rs = oracle.fa_bruteforce(D, d, ones, nthreads=8, want_resid=True)
+    fa_g, km_g, resid = plan.fa_bruteforce(data, None, want_resid=True)
+    assert np.mean(fa_g.cpu().numpy() == idx) > 0.99
+    assert np.allclose(resid.cpu().numpy(), rs, rtol=1e-6, atol=1e-9 * np.abs(rs).max())
