@@ -122,6 +122,7 @@ struct SortBufs {
     int *bucket_start; // [nfa+1]
     int *chunk_start;  // [nfa+1]
     int *queue;        // [1]
+    int *xq;           // [8]  one queue cursor per XCD (unstaged fit kernel)
     int *err;          // [1]  bit0: FA index out of range
 };
 
@@ -453,7 +454,20 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
             __syncthreads();
             c = sI[0];
         } else {
-            if (lane == 0) c = atomicAdd(A.sb.queue, 1);
+            // eight cursors, one per XCD, each over a contiguous eighth of the FA-sorted list: neighbouring voxels are
+            // solved on the same XCD, so their 8-byte outputs (maps, reg, lambda) merge into whole lines in that XCD's L2
+            // before they go to HBM; a wave whose own eighth is used up takes from the next ones
+            c = nchunks;
+            if (lane == 0) {
+                const int xcd = (int)(blockIdx.x & 7u);
+                for (int t = 0; t < 8; ++t) {
+                    const int q = (xcd + t) & 7;
+                    const int qlo = (int)(((int64_t)nchunks * q) >> 3), qhi = (int)(((int64_t)nchunks * (q + 1)) >> 3);
+                    if (qlo >= qhi) continue;
+                    const int i = atomicAdd(A.sb.xq + q, 1);
+                    if (i < qhi - qlo) { c = qlo + i; break; }
+                }
+            }
             c = __builtin_amdgcn_readfirstlane(c);
         }
         MET2_STAT(5, round);
@@ -1097,7 +1111,7 @@ static SortBufs sort_bufs(met2_plan *p)
     const int nf = p->n_fa + 1;
     sb.key = p->dKey; sb.perm = p->dPerm;
     sb.hist = p->dSmall; sb.cursor = p->dSmall + nf; sb.bucket_start = p->dSmall + 2 * nf; sb.chunk_start = p->dSmall + 3 * nf;
-    sb.queue = p->dSmall + 4 * nf; sb.err = p->dSmall + 4 * nf + 1;
+    sb.queue = p->dSmall + 4 * nf; sb.err = p->dSmall + 4 * nf + 1; sb.xq = p->dSmall + 4 * nf + 8;
     return sb;
 }
 
@@ -1341,7 +1355,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dKd, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMemset(p->dKd, 0, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
-    HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 8)));
+    HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1576,7 +1590,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     }
     if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 128, s));
     SortBufs sb = sort_bufs(p);
-    HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 8), s));
+    HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 16), s));
     const int nb = (int)((nvox + 255) / 256);
     // work-queue granularity: 128 voxels per workgroup when D/B are staged per flip angle; otherwise every wave pulls
     // its own voxels -- one at a time for the methods that spend ~1 ms per voxel (X2/L2 on configs[1]: 1 / 2 / 4 / 8 / 16
@@ -1620,6 +1634,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
         hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
                            sig, reg, lam, maps);
         HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 1), s));     // all but the error word
+        HIPCHK(hipMemsetAsync(sb.xq, 0, sizeof(int) * 8, s));
         hipLaunchKernelGGL(requeue_overflow_kernel, dim3(nb), dim3(256), 0, s, nvox, fa_index, status, sb);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
