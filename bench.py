@@ -179,7 +179,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fit_kernel<%s>" % args.method, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "bytes_per_voxel": bpv,
-                         "note": "fp64 VALU-issue-bound active-set iteration (70 % of VALU issue slots, profiles/r01i_x2l2_pmc_sq.csv), not HBM-bound (DESIGN.md section 6)"},
+                         "note": "fp64 VALU-issue-bound active-set iteration (70 % of VALU issue slots, profiles/r01j_x2l2_pmc_sq.csv), not HBM-bound (DESIGN.md section 6)"},
         }
         if brute:
             line["roofline"]["fa_kernel_ms"] = float(np.mean(fa_ms[-args.steps:]))
