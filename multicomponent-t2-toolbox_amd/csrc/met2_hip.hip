@@ -1154,11 +1154,13 @@ static int fast_kmax(const met2_plan *p, int method)
 {
     if (method == MET2_BAYESREG || method == MET2_GCV || method >= 10) return 0;
     if (const char *e = getenv("MET2_KMAX")) { int kk = atoi(e); return (kk >= 8 && kk < p->n_t2) ? kk : 0; }
-    // the largest capacity that still lets 16 waves share the LDS, but not below 0.8 n
-    // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M)
+    // the largest capacity that still lets 16 waves share the LDS, but not below 0.6 n
+    // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M;
+    //  nT2 = 120 with the per-wave queue, where the clean-up pass is cheap: kmax 56 / 64 / 72 / 80 / 96 ->
+    //  320 / 464 / 583 / 534 / 391 k voxels/s at 12 / 9 / 7 / 6 / 4 waves per CU)
     int k16 = 8;
     while (16 * sizeof(double) * (size_t)((k16 + 1) * (k16 + 2) / 2) <= 160 * 1024 - 64) ++k16;
-    int k = (4 * p->n_t2 + 4) / 5;
+    int k = (3 * p->n_t2 + 4) / 5;
     if (k16 > k) k = k16;
     return k < p->n_t2 ? k : 0;
 }
