@@ -1125,7 +1125,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     g.np = n | 1;
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
-    if (method == MET2_GCV && (m + 1) * (n + 2) > g.wave_doubles) g.wave_doubles = (m + 1) * (n + 2);   // E^T (k x (m+1)) + norms + rotation row
+    if (method == MET2_GCV && (m + 1) * (g.kmax + 2) > g.wave_doubles) g.wave_doubles = (m + 1) * (g.kmax + 2);   // E^T (k x (m+1)) + norms + rotation row, k <= kmax
     // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
     // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
     // only ~k rows of B, so the fit kernel prefers the LDS for more resident waves per CU (measured on X2/L2:
@@ -1152,8 +1152,20 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
 // full n x n region (BayesReg) or their own matrix (GCV) do not use it.
 static int fast_kmax(const met2_plan *p, int method)
 {
-    if (method == MET2_BAYESREG || method == MET2_GCV || method >= 10) return 0;
+    if (method == MET2_BAYESREG || method >= 10) return 0;
     if (const char *e = getenv("MET2_KMAX")) { int kk = atoi(e); return (kk >= 8 && kk < p->n_t2) ? kk : 0; }
+    if (method == MET2_GCV) {
+        // GCV's wave region holds the factor or its E^T matrix ((m+1) x (k+2)): the largest capacity that keeps the 12 waves
+        // the kernel is compiled for, but not below 0.6 n (measured: nT2 = 60: 36..48 -> 290 k voxels/s against 270 k at full
+        // capacity; nT2 = 120: 56 / 64 / 72 / 78 / full -> 17.7 / 24.8 / 30.3 / 30.3 / 14.9 k voxels/s)
+        const int mm = p->n_te + 1;
+        auto need = [&](int k) { size_t a = (size_t)k * (k + 1) / 2, b = (size_t)mm * (k + 2); return sizeof(double) * (a > b ? a : b); };
+        int k12 = 8;
+        while (12 * need(k12 + 1) <= 160 * 1024 - 64) ++k12;
+        int k = (3 * p->n_t2 + 4) / 5;
+        if (k12 > k) k = k12;
+        return k < p->n_t2 ? k : 0;
+    }
     // the largest capacity that still lets 16 waves share the LDS, but not below 0.6 n
     // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M;
     //  nT2 = 120 with the per-wave queue, where the clean-up pass is cheap: kmax 56 / 64 / 72 / 80 / 96 ->
