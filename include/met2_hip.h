@@ -161,6 +161,16 @@ int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const doub
                           int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
                           double *fa_index, double *xmin, void *stream);
 
+/* motor:337-343, the Gaussian pre-smoothing of the FA step (FA_smooth='yes', the CLI default): the reference runs
+ * scipy.ndimage.gaussian_filter(volume, 2.0) on every echo volume.  This is the separable filter behind it: one pass per
+ * spatial axis with the symmetric kernel weights[0 .. 2 radius] (HOST array, weights[radius] the centre; for the
+ * reference: radius = int(4 sigma + 0.5), weights = exp(-x^2 / (2 sigma^2)) normalised to sum 1), boundary mode 'reflect',
+ * accumulated in scipy's order, so the result is bit-identical to gaussian_filter.  DEVICE pointers: data and out
+ * [nx][ny][nz][n_te], work the same size (NULL: allocated and freed inside, which makes the call blocking); all distinct.
+ * radius <= 32. */
+int met2_smooth_separable(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t n_te, int32_t radius, const double *weights,
+                          const double *data, double *out, double *work, void *stream);
+
 /* motor:305-333, the NESMA filter (denoise='NESMA').  DEVICE pointers: data [nx][ny][nz][n_te] (already
  * multiplied by the mask and clipped at 0, motor:180-182 and :279), mask [nx][ny][nz] uint8 -- voxels with
  * mask == 1 are filtered (motor:317), all others get zeros (NULL = filter every voxel); out [nx][ny][nz][n_te],

@@ -946,6 +946,52 @@ __global__ __launch_bounds__(256) void nesma_kernel(NesmaArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// Gaussian pre-smoothing of the FA step (motor:337-343: scipy.ndimage.gaussian_filter(vol, 2.0) on every echo volume):
+// one separable pass per axis over the whole [nx][ny][nz][nt] array (nt innermost: all echoes at once, coalesced for
+// every axis), 'reflect' boundary, accumulation in the order of scipy's correlate1d for symmetric kernels (centre, then
+// the pairs from the outermost inwards) with separate multiply and add roundings, so the result is bit-identical.
+// ------------------------------------------------------------------------------------------
+#define MET2_SMOOTH_MAX_RADIUS 32
+struct SmoothArgs {
+    int n, radius;
+    int64_t stride, total;
+    const double *src;
+    double *dst;
+    double w[2 * MET2_SMOOTH_MAX_RADIUS + 1];
+};
+
+__device__ __forceinline__ int reflect_index_dev(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period; if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+__global__ __launch_bounds__(256) void smooth_axis_kernel(SmoothArgs A)
+{
+#pragma clang fp contract(off)                                      // scipy's C loop rounds the product and the sum separately
+    const int r = A.radius, n = A.n;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < A.total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)((idx / A.stride) % n);
+        const double *base = A.src + (idx - (int64_t)i * A.stride);
+        double t = A.src[idx] * A.w[r];
+        if (i >= r && i + r < n) {                                  // interior: no reflection
+            for (int j = -r; j < 0; ++j) {
+                const double pr = (base[(int64_t)(i + j) * A.stride] + base[(int64_t)(i - j) * A.stride]) * A.w[j + r];
+                t = t + pr;
+            }
+        } else {
+            for (int j = -r; j < 0; ++j) {
+                const double pr = (base[(int64_t)reflect_index_dev(i + j, n) * A.stride] + base[(int64_t)reflect_index_dev(i - j, n) * A.stride]) * A.w[j + r];
+                t = t + pr;
+            }
+        }
+        A.dst[idx] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 #define MET2_MAX_LR 32
 struct SplineArgs {
     int nlr, nhr, nte;
@@ -1258,6 +1304,38 @@ static void spline_weights_host(int n, const double *x, std::vector<double> &W)
             for (int q = c + 1; q < n; ++q) t -= A[(size_t)c * n + q] * W[(size_t)q * n + j];
             W[(size_t)c * n + j] = t / A[(size_t)c * n + c];
         }
+}
+
+extern "C" int met2_smooth_separable(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t nt, int32_t radius, const double *weights,
+                                     const double *data, double *out, double *work, void *stream)
+{
+    if (nx < 0 || ny < 0 || nz < 0 || nt < 1) return fail(MET2_E_INVALID, "bad shape");
+    if (radius < 0 || radius > MET2_SMOOTH_MAX_RADIUS) return fail(MET2_E_UNSUPPORTED, "kernel radius must be 0..32");
+    const int64_t total = (int64_t)nx * ny * nz * nt;
+    if (total == 0) return MET2_OK;
+    if (!weights || !data || !out) return fail(MET2_E_INVALID, "NULL argument");
+    if (data == out || work == out || work == data) return fail(MET2_E_INVALID, "data, out and work must be distinct");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    double *tmp = work;
+    if (!tmp) HIPCHK(hipMalloc(&tmp, sizeof(double) * (size_t)total));
+    SmoothArgs A;
+    A.radius = radius; A.total = total;
+    for (int i = 0; i < 2 * radius + 1; ++i) A.w[i] = weights[i];
+    const int dims[3] = {nx, ny, nz};
+    const int64_t strides[3] = {(int64_t)ny * nz * nt, (int64_t)nz * nt, (int64_t)nt};
+    const double *src = data;
+    double *dst = out;                                              // x: data -> out, y: out -> work, z: work -> out
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    for (int ax = 0; ax < 3; ++ax) {
+        A.n = dims[ax]; A.stride = strides[ax]; A.src = src; A.dst = dst;
+        hipLaunchKernelGGL(smooth_axis_kernel, dim3(grid), dim3(256), 0, s, A);
+        src = dst;
+        dst = (dst == out) ? tmp : out;
+    }
+    HIPCHK(hipGetLastError());
+    if (!work) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(tmp)); }
+    return MET2_OK;
 }
 
 extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t nt, const double *data,

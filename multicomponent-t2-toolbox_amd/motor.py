@@ -83,13 +83,39 @@ def nesma_filter(data, mask, device=0):
     return out.cpu().numpy() if as_numpy else out
 
 
+def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
+    """The Gaussian pre-smoothing of the FA step (motor:337-343): every echo volume of data [nx,ny,nz,nt] through the
+    equivalent of scipy.ndimage.gaussian_filter(volume, sigma) (mode 'reflect', truncate 4), on the device, bit-identical
+    to scipy.  numpy in -> numpy out, CUDA tensor in -> tensor out."""
+    as_numpy = not torch.is_tensor(data)
+    dev = torch.device("cuda", device) if as_numpy else data.device
+    dd = torch.as_tensor(data, dtype=torch.float64, device=dev).contiguous()
+    if dd.dim() != 4:
+        raise ValueError("data must be [nx,ny,nz,nt]")
+    radius = int(truncate * float(sigma) + 0.5)                      # scipy.ndimage.gaussian_filter1d
+    x = np.arange(-radius, radius + 1)
+    w = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    w = np.ascontiguousarray(w / w.sum(), dtype=np.float64)
+    out = torch.empty_like(dd)
+    work = torch.empty_like(dd)
+    nx, ny, nz, nt = dd.shape
+    import ctypes as C
+    with torch.cuda.device(dev):
+        check(lib().met2_smooth_separable(dev.index or 0, nx, ny, nz, nt, radius, w.ctypes.data_as(C.POINTER(C.c_double)), dd.data_ptr(),
+                                          out.data_ptr(), work.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.current_stream(dev).synchronize()                 # `work` and the host weights stay alive until here
+    return out.cpu().numpy() if as_numpy else out
+
+
 def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
-                      fa_index=None, device=0, plan=None, denoise="None", prepared=False):
+                      fa_index=None, device=0, plan=None, denoise="None", prepared=False, FA_smooth="no"):
     """Steps 1-4 of motor_recon_met2 (motor:293-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
     [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
     negative values clipped to 0 (motor:279), optional NESMA filter (motor:305-333, needs a 3-D volume),
     Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms, T1 = 1000 ms, 91 flip angles for brute force.
     `prepared=True` says the caller already did that preparation (mask multiply, clip, denoise).
+    FA_smooth='yes' (the CLI default, motor:337-343): the flip angles are estimated on the Gaussian-smoothed volume
+    (sigma = 2 voxels, every echo), the spectra on the unsmoothed one; needs a 3-D volume.
     Returns a dict with the driver's ten outputs."""
     if FA_method not in ("brute-force", "spline"):
         raise ValueError("FA_method must be 'spline' or 'brute-force'")
@@ -112,7 +138,14 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
             if len(vol_shape) != 3:
                 raise ValueError("NESMA needs data [nx,ny,nz,nt]")
             dd = nesma_filter(dd, mk)
+    dd_fa = None
+    if FA_smooth == "yes" and fa_index is None:
+        if len(vol_shape) != 3:
+            raise ValueError("FA_smooth='yes' needs data [nx,ny,nz,nt]")
+        dd_fa = gaussian_smooth(dd.reshape(vol_shape + (nt,)), 2.0).reshape(-1, nt)
     dd = dd.reshape(-1, nt).contiguous()
+    if dd_fa is None:
+        dd_fa = dd
     mm = (mk.reshape(-1) > 0)
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
@@ -131,10 +164,10 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     if spline:
         plan_lr = Met2Plan(nt, Npc, 15, device=device)
         plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_values_spline, TR)
-        fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd, mm)
+        fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd_fa, mm)
         plan_lr.close()
     elif fa_index is None:
-        fa, km, _ = plan.fa_bruteforce(dd, mm)
+        fa, km, _ = plan.fa_bruteforce(dd_fa, mm)
     else:
         fa = torch.as_tensor(np.asarray(fa_index, dtype=np.float64).reshape(-1), device=dev)
     out = plan.fit(reg_method, dd, fa_index=fa, mask=mm)
@@ -142,7 +175,7 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
            "Est_Signal": out["sig"].cpu().numpy().reshape(vol_shape + (nt,)),
            "reg_param": out["reg"].cpu().numpy().reshape(vol_shape),
            "FA_index": fa.cpu().numpy().reshape(vol_shape)}
-    fitted_fa = (mm & (dd.sum(dim=1) > 0)).cpu().numpy().reshape(vol_shape)
+    fitted_fa = (mm & (dd_fa.sum(dim=1) > 0)).cpu().numpy().reshape(vol_shape)      # gate of the FA step (fa_estimation.py:45)
     res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
     maps = out["maps"].cpu().numpy()
     for i, name in enumerate(MAP_NAMES):
@@ -168,22 +201,8 @@ def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR
     mask = nifti.load(path_to_mask).get_fdata().astype(np.int64)
     if data.ndim != 4 or mask.shape != data.shape[:3]:
         raise ValueError("data must be 4-D and mask must match its first three dimensions")
-    fa_index = None
-    dm = data * mask[..., None]                       # motor:180-182
-    dm[dm < 0.0] = 0.0                                # motor:279
-    if denoise == "NESMA":
-        dm = nesma_filter(dm, mask, device=device)    # motor:305-333
-    if FA_smooth == "yes":
-        # motor:337-343: the flip angle is estimated on Gaussian-smoothed data (sigma 2 voxels), the spectra on the unsmoothed data
-        import scipy.ndimage as filt
-        sm = np.stack([filt.gaussian_filter(dm[..., c], 2.0, 0) for c in range(dm.shape[-1])], axis=-1)
-        pre = recon_met2_arrays(sm, mask, TE_array, TR, "NNLS", reg_matrix, FA_method, myelin_T2, device=device, prepared=True)
-        fa_index = pre["FA_index"]
-    res = recon_met2_arrays(dm, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index=fa_index, device=device,
-                            prepared=True)
-    if fa_index is not None:
-        n_alpha = 91 * 3 if FA_method == "spline" else 91
-        res["FA"] = np.where(mask > 0, np.linspace(90.0, 180.0, n_alpha)[np.asarray(fa_index).astype(int)], 0.0)
+    res = recon_met2_arrays(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, device=device, denoise=denoise,
+                            FA_smooth=FA_smooth)
     for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
         nifti.save(nifti.NiftiImage(res[name], img.affine), path_to_save_data + name + ".nii.gz")
     return res

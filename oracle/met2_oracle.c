@@ -25,6 +25,8 @@
  *   motor/motor_recon_met2_real_data.py:443-472 -> met2o_metrics
  *   flip_angle_algorithms/fa_estimation.py:74-90 -> met2o_fa_bruteforce
  *   motor/motor_recon_met2_real_data.py:305-333 -> met2o_nesma
+ *   motor/motor_recon_met2_real_data.py:337-343 -> met2o_gaussian_smooth (scipy.ndimage.gaussian_filter, SciPy 1.x:
+ *       gaussian_filter1d per axis = correlate1d with the normalised kernel, mode 'reflect', truncate 4)
  *   flip_angle_algorithms/fa_estimation.py:35-70 -> met2o_fa_spline (scipy interp1d(kind='cubic') =
  *        not-a-knot cubic spline; scipy minimize_scalar(method='Bounded') = the same bounded Brent)
  */
@@ -1065,6 +1067,54 @@ MET2O_API void met2o_nesma(int nx, int ny, int nz, int nt, const double *data, c
                 }
         free(diff); free(acc);
     }
+}
+
+/* ------------------------------------------------------------------ Gaussian pre-smoothing for the FA step (motor:337-343) */
+/* scipy.ndimage 'reflect' extension (d c b a | a b c d | d c b a), any offset */
+static int reflect_index(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period; if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+/* data, out [nx][ny][nz][nt]; every echo volume filtered along x, then y, then z with the symmetric kernel w[0..2r]
+ * (w[r] the centre), accumulated as scipy's correlate1d does for symmetric kernels: centre first, then the pairs from
+ * the outermost inwards. */
+MET2O_API void met2o_gaussian_smooth(int nx, int ny, int nz, int nt, int radius, const double *w, const double *data, double *out, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const size_t total = (size_t)nx * ny * nz * nt;
+    double *tmp = (double *)malloc(sizeof(double) * total);
+    const int dims[3] = {nx, ny, nz};
+    const size_t strides[3] = {(size_t)ny * nz * nt, (size_t)nz * nt, (size_t)nt};
+    const double *src = data;
+    double *dst = out;
+    for (int ax = 0; ax < 3; ++ax) {
+        const int n = dims[ax];
+        const size_t st = strides[ax];
+        const size_t nlines = total / (size_t)n;
+#pragma omp parallel for schedule(static)
+        for (long long line = 0; line < (long long)nlines; ++line) {
+            /* decompose the line index into the offset of its first element */
+            size_t inner = (size_t)line % st, outer = (size_t)line / st;
+            const double *s0 = src + outer * st * (size_t)n + inner;
+            double *d0 = dst + outer * st * (size_t)n + inner;
+            for (int i = 0; i < n; ++i) {
+                double t = s0[(size_t)i * st] * w[radius];
+                for (int j = -radius; j < 0; ++j)
+                    t += (s0[(size_t)reflect_index(i + j, n) * st] + s0[(size_t)reflect_index(i - j, n) * st]) * w[j + radius];
+                d0[(size_t)i * st] = t;
+            }
+        }
+        /* ping-pong: x: data -> out, y: out -> tmp, z: tmp -> out */
+        src = dst;
+        dst = (dst == out) ? tmp : out;
+    }
+    free(tmp);
 }
 
 MET2O_API int met2o_max_threads(void)

@@ -228,5 +228,25 @@ def nesma(data, mask, nthreads=1):
     return out
 
 
+def gaussian_kernel1d(sigma, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, int(truncate * sigma + 0.5)) -- the reference calls
+    gaussian_filter(vol, 2.0, 0) (motor:342); returns (radius, weights)"""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    return radius, phi / phi.sum()
+
+
+def gaussian_smooth(data, sigma=2.0, nthreads=1):
+    """motor:337-343: every echo volume of data [nx,ny,nz,nt] through scipy.ndimage.gaussian_filter(sigma)"""
+    data = _d(data)
+    nx, ny, nz, nt = data.shape
+    r, w = gaussian_kernel1d(sigma)
+    w = _d(w)
+    out = np.zeros_like(data)
+    lib().met2o_gaussian_smooth(nx, ny, nz, nt, r, _p(w), _p(data), _p(out), int(nthreads))
+    return out
+
+
 def max_threads():
     return lib().met2o_max_threads()

@@ -12,10 +12,16 @@ data, _, _ = synth.make_voxels(nvox, nte=32, seed=9, fa_values=alphas, device="c
 data = data.cpu().numpy().reshape(dims + (32,))
 mask = np.ones(dims, dtype=np.int64)
 TE = 10.0 * np.arange(1, 33)
-for fa_method in ("spline", "brute-force"):
+for fa_method, smooth in (("spline", "yes"), ("spline", "no"), ("brute-force", "no")):
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = motor.recon_met2_arrays(data, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0)
+        res = motor.recon_met2_arrays(data, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, FA_smooth=smooth)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"driver": "recon_met2_arrays", "dims": dims, "FA_method": fa_method, "seconds": dt, "voxels_per_s": nvox / dt,
-                      "MWF_mean": float(res["MWF"].mean())}))
+    print(json.dumps({"driver": "recon_met2_arrays", "dims": dims, "FA_method": fa_method, "FA_smooth": smooth, "seconds": dt,
+                      "voxels_per_s": nvox / dt, "MWF_mean": float(res["MWF"].mean())}))
+d4 = torch.as_tensor(data, device="cuda")
+motor.gaussian_smooth(d4, 2.0); torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3):
+    motor.gaussian_smooth(d4, 2.0)
+torch.cuda.synchronize()
+print(json.dumps({"kernel": "gaussian_smooth (3 axis passes, sigma 2)", "dims": dims, "ms": (time.perf_counter() - t0) / 3 * 1e3}))

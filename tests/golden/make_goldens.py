@@ -415,9 +415,54 @@ def gen_nesma(seed):
     print("wrote golden_nesma.npz")
 
 
+def gen_smooth(seed):
+    """The CLI's default pipeline (run_real_data_script.py:32-46: FA_method='spline', FA_smooth='yes', denoise='None', X2):
+    the driver smooths every echo volume with scipy.ndimage.gaussian_filter(sigma=2) for the FA step only
+    (motor:337-343).  The rows handed to the spline FA step are recorded (= the smoothed volume) next to the outputs."""
+    from epg.epg import epg_signal
+    import motor.motor_recon_met2_real_data as motor
+    import matplotlib
+    matplotlib.rcParams["text.usetex"] = False
+    rng = np.random.default_rng(seed)
+    nx, ny, nz, nte = 7, 6, 5, 32
+    data, _ = synth_voxels(rng, nx * ny * nz, nte, epg_signal, fa_deg=None)
+    data = data.reshape(nx, ny, nz, nte)
+    mask = np.ones((nx, ny, nz)); mask[0, 0, 0] = 0; mask[6, 5, 4] = 0; mask[3, 2, :] = 0
+    _NIB_FILES["sm_data"] = data
+    _NIB_FILES["sm_mask"] = mask
+    rows = {}
+    orig = motor.fitting_slice_FA_spline_method
+    state = {"z": -1, "y": 0}
+
+    def spy(Dic_3D_LR, Dic_3D, data_1d, mask_1d, alpha_values_spline, nx_, alpha_values):
+        if state["y"] == 0:
+            state["z"] += 1
+        rows[(state["y"], state["z"])] = np.array(data_1d)
+        state["y"] = (state["y"] + 1) % ny
+        return orig(Dic_3D_LR, Dic_3D, data_1d, mask_1d, alpha_values_spline, nx_, alpha_values)
+
+    motor.fitting_slice_FA_spline_method = spy
+    TE = 10.0 * np.arange(1, nte + 1)
+    os.makedirs("/tmp/met2_golden_png", exist_ok=True)
+    prefix = "/tmp/met2_golden_png/smooth_"
+    try:
+        with np.errstate(all="ignore"):
+            motor.motor_recon_met2(TE, "sm_data", "sm_mask", prefix, 3000.0, "X2", "L2", "None", "spline", "yes", 40.0, 1)
+    finally:
+        motor.fitting_slice_FA_spline_method = orig
+    sm = np.zeros_like(data)
+    for (y, z), r in rows.items():
+        sm[:, y, z, :] = r
+    out = {"data": data, "mask": mask, "TE": TE, "smoothed": sm}
+    for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
+        out[name] = _NIB_FILES[prefix + name + ".nii.gz"]
+    np.savez_compressed(os.path.join(HERE, "golden_motor_default_smooth.npz"), **out)
+    print("wrote golden_motor_default_smooth.npz", sm.shape, float(np.abs(sm - data * mask[..., None]).max()))
+
+
 def main():
     install_shims()
-    which = sys.argv[1:] or ["S1", "S2", "motor", "nesma"]
+    which = sys.argv[1:] or ["S1", "S2", "motor", "nesma", "smooth"]
     if "S1" in which:
         gen_shape("S1", 32, 60, nvox=32, nvox_slow=32, seed=20260101, with_fa_full=True)
     if "S2" in which:
@@ -427,6 +472,8 @@ def main():
         gen_motor("lcurve_l1_spline", "L_curve", "L1", "spline", 20260112)
     if "nesma" in which:
         gen_nesma(20260113)
+    if "smooth" in which:
+        gen_smooth(20260114)
 
 
 if __name__ == "__main__":

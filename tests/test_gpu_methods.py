@@ -306,6 +306,44 @@ def test_nesma_errors(pkg):
     assert motor.nesma_filter(np.zeros((0, 3, 3, 8)), np.ones((0, 3, 3))).shape == (0, 3, 3, 8)
 
 
+def test_gaussian_smooth_and_default_pipeline_golden(pkg, tmp_path):
+    # the CLI's default pipeline (spline FA on Gaussian-smoothed echoes, X2/L2 on the unsmoothed ones; motor:337-343):
+    # the device filter is bit-identical to scipy.ndimage.gaussian_filter and to the rows the reference's driver used,
+    # and the whole run reproduces the reference's maps
+    import torch
+    import scipy.ndimage as filt
+    motor = importlib.import_module(PKG + ".motor")
+    nifti = importlib.import_module(PKG + ".nifti")
+    g = np.load(os.path.join(GOLDEN, "golden_motor_default_smooth.npz"))
+    dm = g["data"] * g["mask"][..., None]
+    dm = np.where(dm < 0, 0.0, dm)
+    assert np.array_equal(motor.gaussian_smooth(dm, 2.0), g["smoothed"])
+    rng = np.random.default_rng(8)
+    for shp in [(33, 7, 20, 3), (1, 2, 3, 4), (12, 40, 5, 32)]:
+        d = rng.standard_normal(shp)
+        ref = np.stack([filt.gaussian_filter(d[..., c], 2.0, 0) for c in range(shp[-1])], axis=-1)
+        got = motor.gaussian_smooth(torch.as_tensor(d, device="cuda"), 2.0)
+        assert np.array_equal(got.cpu().numpy(), ref), shp
+    res = motor.recon_met2_arrays(g["data"], g["mask"], g["TE"], 3000.0, "X2", "L2", "spline", 40.0, FA_smooth="yes")
+    assert np.array_equal(res["FA"], g["FA"])
+    assert relmax(res["fsol_4D"], g["fsol_4D"]) < TOL
+    assert relmax(res["Est_Signal"], g["Est_Signal"]) < TOL
+    assert np.allclose(res["reg_param"], g["reg_param"], rtol=1e-4, atol=1e-12)
+    for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
+        assert np.max(np.abs(res[name] - g[name])) / max(1.0, np.max(np.abs(g[name]))) < TOL, name
+    # the same through the on-disk driver
+    aff = np.eye(4)
+    nifti.save(nifti.NiftiImage(g["data"], aff), str(tmp_path / "data.nii.gz"))
+    nifti.save(nifti.NiftiImage(g["mask"].astype(np.uint8), aff), str(tmp_path / "mask.nii.gz"))
+    out = str(tmp_path) + "/default_"
+    motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "None",
+                           "spline", "yes", 40.0, 1)
+    assert np.array_equal(nifti.load(out + "FA.nii.gz").get_fdata(), g["FA"])
+    assert np.max(np.abs(nifti.load(out + "MWF.nii.gz").get_fdata() - g["MWF"])) < TOL
+    with pytest.raises(pkg.Met2Error):
+        motor.gaussian_smooth(np.zeros((2, 2, 2, 2)), sigma=9.0)        # radius 36 > 32
+
+
 def test_roi_mode_x2(pkg):
     # ROI-mode fits (motor_recon_met2_real_data_ROI.py:405-443): mean signal, mean kernel, X2 with factor 1.01
     from oracle import oracle

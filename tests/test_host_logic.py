@@ -149,6 +149,36 @@ def test_oracle_nesma_edge_cases(oracle):
         assert np.array_equal(oracle.nesma(d, m), ref), nt
 
 
+def test_oracle_gaussian_smooth_vs_scipy_and_driver(oracle):
+    # SURVEY.md §8f item 1, second half: the Gaussian pre-smoothing of the FA step (motor:337-343).  The restatement is
+    # pinned to scipy.ndimage.gaussian_filter itself (the reference's dependency, present here) and to the rows the
+    # reference's driver handed to its spline FA step in a run with the CLI defaults (spline, FA_smooth='yes', X2)
+    import scipy.ndimage as filt
+    rng = np.random.default_rng(3)
+    for shp in [(3, 1, 2, 4), (20, 17, 9, 5), (1, 1, 1, 3), (9, 30, 4, 2), (2, 2, 40, 1)]:
+        d = rng.standard_normal(shp)
+        ref = np.stack([filt.gaussian_filter(d[..., c], 2.0, 0) for c in range(shp[-1])], axis=-1)
+        assert np.array_equal(oracle.gaussian_smooth(d, 2.0, nthreads=2), ref), shp
+    g = np.load(os.path.join(GOLDEN, "golden_motor_default_smooth.npz"))
+    dm = g["data"] * g["mask"][..., None]
+    dm = np.where(dm < 0, 0.0, dm)
+    sm = oracle.gaussian_smooth(dm, 2.0, nthreads=4)
+    assert np.array_equal(sm, g["smoothed"])
+    # the default pipeline end to end: spline FA on the smoothed rows, X2/L2 on the unsmoothed ones
+    shp = g["mask"].shape; nt = dm.shape[-1]
+    m1 = (g["mask"].reshape(-1) > 0).astype(float)
+    T2s = np.logspace(1, np.log10(2000.0), 60); T1s = 1000.0 * np.ones(60)
+    ah = np.linspace(90.0, 180.0, 273); al = np.linspace(90.0, 180.0, 15)
+    Dh = oracle.dictionary_fa_major(60, T2s, T1s, nt, 10.0, ah, 3000.0)
+    Dl = oracle.dictionary_fa_major(60, T2s, T1s, nt, 10.0, al, 3000.0)
+    idx, km, xm = oracle.fa_spline(Dl, al, Dh, ah, sm.reshape(-1, nt), m1, nthreads=4)
+    fitted = (m1 > 0) & (sm.reshape(-1, nt).sum(axis=1) > 0)
+    assert np.array_equal(np.where(fitted, ah[idx.astype(int)], 0.0).reshape(shp), g["FA"])
+    fs, sg, rg, st = oracle.fit_batch("X2", Dh, oracle.penalty(60, "L2", T2s), dm.reshape(-1, nt), idx, m1, nthreads=4)
+    assert relmax(fs.reshape(shp + (60,)), g["fsol_4D"]) < 1e-8
+    assert np.allclose(oracle.metrics(fs, T2s, m1)["MWF"].reshape(shp), g["MWF"], rtol=1e-8, atol=1e-12)
+
+
 def test_spline_weights_match_scipy(oracle):
     # interp1d(kind='cubic') is the not-a-knot cubic spline: same interpolant from the slope form
     from scipy.interpolate import interp1d
