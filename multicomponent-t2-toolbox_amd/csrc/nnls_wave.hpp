@@ -802,9 +802,16 @@ __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsSt
 template <int NB>
 __device__ __forceinline__ double sse_of(const WaveShared &S, const NnlsState<NB> &st, double b, int lane)
 {
+#ifdef MET2_CYCSTATS
+    const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
     double r = model_signal<NB>(S, st, lane) - b;
     r = (lane < S.m) ? r : 0.0;
-    return wave_sum(r * r);
+    const double out = wave_sum(r * r);
+#ifdef MET2_CYCSTATS
+    const_cast<NnlsState<NB> &>(st).cyc[5] += __builtin_readcyclecounter() - c0;
+#endif
+    return out;
 }
 
 // h = D^T b for the bins a lane owns (bvec: lane e holds echo e)
