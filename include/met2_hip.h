@@ -8,7 +8,8 @@
  * reference would add.  Plain pointers and sizes only -- no torch types.
  *
  * Conventions
- *   - all arithmetic is IEEE fp64;
+ *   - all arithmetic is fp64 (fused multiply-adds; the factorisation's reciprocal square roots are v_rsq_f64 plus two
+ *     Newton steps, ~1 ulp; the lambda search and its objective use IEEE division and square root);
  *   - "host" pointers are ordinary process memory (small parameter arrays);
  *     "device" pointers are HIP device memory on the plan's device (bulk voxel arrays);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
