@@ -1,0 +1,16 @@
+"""Time the coarse (15-angle) FA walk of the spline method on 1 048 576 voxels."""
+import importlib, json, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+pkg = importlib.import_module("multicomponent-t2-toolbox_amd")
+synth = importlib.import_module("multicomponent-t2-toolbox_amd.synth")
+nvox = 128 * 128 * 64; nt = 32
+T2s = synth.t2_grid(60); T1s = 1000.0 * np.ones(60)
+nfa = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+al = np.linspace(90.0, 180.0, nfa)
+pl = pkg.Met2Plan(nt, 60, nfa); pl.build_dictionary_epg(T2s, T1s, 10.0, al, 3000.0)
+data, _, _ = synth.make_voxels(nvox, nte=nt, seed=9, fa_values=np.linspace(90.0, 180.0, 91), device="cuda")
+for rep in range(3):
+    fa, km, resid = pl.fa_bruteforce(data, None, want_resid=True)
+    torch.cuda.synchronize()
+print(json.dumps({"kernel": "fa walk", "nfa": nfa, "nvox": nvox, "ms": pl.last_kernel_ms(), "resid_checksum": float(resid.sum())}))
