@@ -166,6 +166,18 @@ def main():
                 traffic = json.load(open(tfile)).get("%s_%s_bytes_per_launch" % (args.method, args.penalty)) if (nte, nt2, nvox) == (32, 60, 1048576) else None
             except Exception:
                 traffic = None
+        # the resource that actually binds: fp64 VALU issue.  Instructions per launch from the committed PMC pass of this
+        # workload (SQ_INSTS_VALU; one wave64 VALU instruction = 4 cycles of a 16-lane SIMD), time measured live.
+        valu = None
+        sqfile = os.path.join(ROOT, "profiles", "r01j_x2l2_pmc_sq.csv")
+        if os.path.exists(sqfile) and (nte, nt2, nvox, args.method, args.penalty, brute) == (32, 60, 1048576, "X2", "L2", False):
+            try:
+                n_valu = [float(l.split(",")[-1]) for l in open(sqfile) if ",SQ_INSTS_VALU," in l][0]
+                simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+                valu = {"valu_insts_per_launch": n_valu, "simds": simds, "clock_ghz": 2.4,
+                        "valu_issue_frac": n_valu * 4.0 / (simds * kms * 1e-3 * 2.4e9)}
+            except Exception:
+                valu = None
         line = {
             "metric": "voxels/sec (whole node) at nTE=32, nT2=60; max |MWF-ref|",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,6 +193,8 @@ def main():
                          "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "bytes_per_voxel": bpv,
                          "note": "fp64 VALU-issue-bound active-set iteration (70 % of VALU issue slots, profiles/r01j_x2l2_pmc_sq.csv), not HBM-bound (DESIGN.md section 6)"},
         }
+        if valu:
+            line["roofline"]["valu"] = valu
         if brute:
             line["roofline"]["fa_kernel_ms"] = float(np.mean(fa_ms[-args.steps:]))
         if not args.no_cpu_baseline and not brute:
