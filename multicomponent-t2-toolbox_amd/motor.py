@@ -164,7 +164,7 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     if spline:
         plan_lr = Met2Plan(nt, Npc, 15, device=device)
         plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_values_spline, TR)
-        fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd_fa, mm)
+        fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd_fa, mm, want_km=False)
         plan_lr.close()
     elif fa_index is None:
         fa, km, _ = plan.fa_bruteforce(dd_fa, mm)

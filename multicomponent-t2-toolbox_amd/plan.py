@@ -168,7 +168,7 @@ class Met2Plan:
             check(lib().met2_fa_bruteforce(self._h, nvox, _ptr(data), _ptr(mask), _ptr(fa), _ptr(km), _ptr(resid), self._stream()))
         return fa, km, resid
 
-    def fa_spline(self, plan_lr, alpha_lr, alpha_hr, data, mask=None, want_xmin=False):
+    def fa_spline(self, plan_lr, alpha_lr, alpha_hr, data, mask=None, want_xmin=False, want_km=True):
         """Spline FA method (fa_estimation.py:35-70): `plan_lr` holds the coarse-grid dictionary (15 flip angles in the
         driver, motor:237-238), this plan the fine one (273).  Returns (fa_index into alpha_hr, km, xmin or None)."""
         assert data.is_cuda and data.dtype == torch.float64 and data.shape[1] == self.n_te
@@ -183,6 +183,8 @@ class Met2Plan:
         with torch.cuda.device(dev):
             check(lib().met2_fa_spline_select(dev.index or 0, nvox, al.shape[0], pal, _ptr(resid), ah.shape[0], pah, self.n_te, _ptr(data),
                                               _ptr(mk), _ptr(fa), _ptr(xmin), self._stream()))
+        if not want_km:                       # the volume driver never uses it (its Ktotal comes from the final spectra, motor:455-468)
+            return fa, None, xmin
         # km = sum of the plain-NNLS spectrum at the selected flip angle (fa_estimation.py:61-64)
         gate = (data.sum(dim=1) > 0) if mk is None else ((data.sum(dim=1) > 0) & (mk != 0))
         out = self.fit("NNLS", data, fa_index=fa, mask=gate, want_sig=False, want_maps=False, want_status=False)
