@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MET2_ABI_VERSION 1
+#define MET2_ABI_VERSION 2
 
 /* reg_method of motor/motor_recon_met2_real_data.py:134-150 */
 enum met2_method {
@@ -137,6 +137,16 @@ int met2_fit(met2_plan *plan, int32_t method, int64_t nvox, const double *data, 
              const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
              int32_t *status, void *stream);
 
+/* The same with an explicit layout of `data`: echo e of voxel v is read at data[v * voxel_stride + e * echo_stride]
+ * (strides in doubles).  The driver loads its volume with nibabel (motor:167-173), whose arrays are Fortran-ordered:
+ * for such an [nx][ny][nz][nt] array voxel_stride = 1 and echo_stride = nx*ny*nz, and voxel v is the voxel at
+ * x + nx*(y + ny*z) -- the outputs then come out in that (Fortran) voxel order, i.e. fsol is the Fortran-ordered
+ * [nx][ny][nz] volume of spectra.  met2_fit is the special case voxel_stride = n_te, echo_stride = 1.  The classify pass
+ * and the solver read every echo exactly once either way; no transposed copy is made. */
+int met2_fit_strided(met2_plan *plan, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
+                     int64_t echo_stride, const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg,
+                     double *lam, double *maps, int32_t *status, void *stream);
+
 /* Test/diagnostic entry: `method` = 10 + MET2_X2 / MET2_GCV / MET2_BAYESREG passed to met2_fit
  * evaluates that method's lambda-selection objective (algorithms.py:226-233, :285-296,
  * bayesian_interpolation.py:107-126) on the plan's lambda grid (n <= n_t2 points) and stores the
@@ -150,6 +160,9 @@ int met2_fit(met2_plan *plan, int32_t method, int64_t nvox, const double *data, 
 int met2_fa_bruteforce(met2_plan *plan, int64_t nvox, const double *data, const uint8_t *mask,
                        double *fa_index, double *km, double *resid, void *stream);
 
+int met2_fa_bruteforce_strided(met2_plan *plan, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                               const uint8_t *mask, double *fa_index, double *km, double *resid, void *stream);
+
 /* flip_angle_algorithms/fa_estimation.py:54-59, the selection step of the spline FA method (the CLI default,
  * run_real_data_script.py:34): given the plain-NNLS residual norms on a coarse FA grid (`resid` from
  * met2_fa_bruteforce on a plan built with the coarse grid, motor:237-238), interpolate them with a cubic
@@ -161,6 +174,10 @@ int met2_fa_bruteforce(met2_plan *plan, int64_t nvox, const double *data, const 
 int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
                           int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
                           double *fa_index, double *xmin, void *stream);
+
+int met2_fa_spline_select_strided(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
+                                  int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, int64_t voxel_stride,
+                                  int64_t echo_stride, const uint8_t *mask, double *fa_index, double *xmin, void *stream);
 
 /* motor:337-343, the Gaussian pre-smoothing of the FA step (FA_smooth='yes', the CLI default): the reference runs
  * scipy.ndimage.gaussian_filter(volume, 2.0) on every echo volume.  This is the separable filter behind it: one pass per
@@ -182,6 +199,18 @@ int met2_smooth_separable(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
 int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t n_te, const double *data,
                const uint8_t *mask, double *out, void *stream);
 
+/* motor/motor_recon_met2_real_data_ROI.py:405-420, the reduction of the ROI mode: for every ROI the mean signal over its
+ * voxels and the mean EPG kernel, each voxel contributing the dictionary slice of its own flip angle
+ * (total_signal / nv, total_Kernel / nv).  `src` holds the dictionary the flip angles index; `dst` is a plan of the same
+ * n_te x n_t2 with n_fa = number of ROIs: its dictionary (and Gram matrices) become the per-ROI mean kernels, so that
+ * met2_fit(dst, MET2_X2, nroi, mean_signal, fa_index = 0..nroi-1, ...) is the per-ROI fit of :419.
+ * DEVICE pointers: data (echo e of voxel v at data[v * voxel_stride + e * echo_stride]), roi_index [nvox] int32 ROI
+ * ordinal 0..nroi-1 (negative: voxel belongs to no ROI), fa_index [nvox] float64 (NULL = 0), out mean_signal
+ * [nroi][n_te], out count [nroi] float64 voxels per ROI (0 -> that ROI's outputs are nan, as in the reference).
+ * Deterministic (fixed summation order).  Blocking. */
+int met2_roi_reduce(met2_plan *src, met2_plan *dst, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                    const int32_t *roi_index, const double *fa_index, double *mean_signal, double *count, void *stream);
+
 /* motor:443-472 alone (fsol already on the device). */
 int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps,
                  void *stream);
@@ -189,8 +218,9 @@ int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_
 /* Duration in ms of the solver kernel of the most recent met2_fit / met2_fa_bruteforce on
  * this plan, measured with HIP events on the launch stream (blocks until it finished). */
 int met2_plan_last_kernel_ms(met2_plan *plan, double *ms);
-/* NNLS/T2SPARC/X2/L-curve fits run in two passes: the solver kernel with a passive-set capacity of 0.8 n_t2
- * (more resident waves per CU), then the same kernel at full capacity for the voxels that hit the cap.
+/* NNLS/T2SPARC/X2/L-curve/GCV fits run in two passes: the solver kernel with a reduced passive-set capacity (the
+ * largest that lets 16 waves share a CU's LDS, never below 0.6 n_t2: 50 at n_t2 = 60, 72 at 120 -- more resident waves
+ * per CU), then the same kernel at full capacity for the voxels that hit the cap (~1 %).
  * met2_plan_last_kernel_ms times the first (dominant) launch; this gives the second pass (requeue + launch),
  * 0 when there was none. */
 int met2_plan_last_second_pass_ms(met2_plan *plan, double *ms);

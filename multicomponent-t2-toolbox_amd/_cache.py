@@ -1,12 +1,13 @@
 """Plan cache for the per-function drop-ins (nnls_x2(D, M, L, ...) style calls hand over the
 dictionary and penalty on every call; the device copies are reused when they are unchanged)."""
 import hashlib
+from collections import OrderedDict
 
 import numpy as np
 
 from .plan import Met2Plan
 
-_PLANS = {}
+_PLANS = OrderedDict()        # least recently used first
 _MAX = 8
 
 
@@ -29,9 +30,13 @@ def plan_for(Dic_3D, Laplac=None, lambda_reg=None, T2s=None):
         D3 = D3[:, :, None]
     k = _key(D3, Laplac, lambda_reg)
     p = _PLANS.get(k)
-    if p is None:
+    if p is not None:
+        _PLANS.move_to_end(k)
+    else:
         if len(_PLANS) >= _MAX:
-            _PLANS.pop(next(iter(_PLANS))).close()
+            # evicted plans are dropped, not closed: a caller may still hold one (fitting_slice_FA_spline_method keeps the
+            # coarse plan while it asks for the fine one); Met2Plan.__del__ frees the device memory with the last reference
+            _PLANS.popitem(last=False)
         p = Met2Plan(D3.shape[0], D3.shape[1], D3.shape[2])
         p.set_dictionary(np.ascontiguousarray(D3))
         if Laplac is not None:

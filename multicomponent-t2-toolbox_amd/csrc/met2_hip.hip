@@ -4,11 +4,17 @@
 //   epg_dictionary_kernel   epg/epg.py:47-162      one wavefront per (T2, flip angle); the EPG
 //                                                  coherence orders live on the lanes, the
 //                                                  shift operator is a lane shuffle
-//   gram_kernel             B_fa = D_fa^T D_fa     (shared design-matrix Gram, once per plan)
-//   classify/scan/scatter   gates of motor:124,131 + counting sort of voxels by FA index so
-//                           that a workgroup stages one flip angle's D and B in LDS
-//   fit_kernel<METHOD>      motor:113-162 + motor:443-472: one voxel per wavefront, persistent
-//                           workgroups pulling FA-homogeneous chunks from an atomic queue
+//   gram_kernel             B_fa = D_fa^T D_fa, D_fa^T   (once per plan)
+//   classify/scan/scatter   gates of motor:124,131 + counting sort of voxels by FA index, so that
+//                           neighbouring entries of the work list read the same D / B rows from L2
+//   fit_kernel<METHOD>      motor:113-162 + motor:443-472: one voxel per wavefront; every wave of the
+//                           persistent workgroups pulls its own voxels from per-XCD queue cursors over
+//                           the FA-sorted list; D, D^T, B and K rows are read through L1/L2 (the
+//                           LDS-staged variant, STAGE = true, is kept behind MET2_STAGE=1)
+//   fa_kernel               fa_estimation.py:74-111: brute force over the plan's flip angles
+//   fa_spline_kernel        fa_estimation.py:54-59
+//   roi_reduce / roi_kernel motor_recon_met2_real_data_ROI.py:405-420: per-ROI mean signal and mean kernel
+//   nesma_kernel, smooth_axis_kernel   motor:305-343
 //   finalize_unfitted       zeros / all-zero-spectrum metrics for gated-out voxels
 //   metrics_kernel          motor:443-472 standalone
 #include <hip/hip_runtime.h>
@@ -31,6 +37,21 @@ using namespace met2;
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// makes `dev` current for the duration of a C-ABI call and puts the caller's device back afterwards
+struct DevGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DevGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev); else if (err == hipSuccess) prev = -1;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define USE_DEVICE(dev)                                                                                \
+    DevGuard dev_guard_(dev);                                                                          \
+    if (dev_guard_.err != hipSuccess) return fail(MET2_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(dev_guard_.err))
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -127,6 +148,7 @@ struct SortBufs {
 };
 
 __global__ __launch_bounds__(256) void classify_kernel(int64_t nvox, int nte, int nfa, const double *__restrict__ data,
+                                                       int64_t vs, int64_t es,      // element strides of data: voxel, echo
                                                        const double *__restrict__ fa_index, const uint8_t *__restrict__ mask,
                                                        int require_first_echo, SortBufs sb, int32_t *__restrict__ status)
 {
@@ -134,9 +156,9 @@ __global__ __launch_bounds__(256) void classify_kernel(int64_t nvox, int nte, in
     int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int key = -1, st = 0;
     if (v < nvox) {
-        const double *M = data + (size_t)v * nte;
+        const double *M = data + v * vs;
         double sum = 0.0; bool finite = true;
-        for (int e = 0; e < nte; ++e) { double t = M[e]; sum += t; finite = finite && isfinite(t); }
+        for (int e = 0; e < nte; ++e) { double t = M[e * es]; sum += t; finite = finite && isfinite(t); }
         bool mk = mask ? (mask[v] != 0) : true;
         if (!finite) st = MET2_ST_NONFINITE;
         else if (mk && sum > 0.0 && (!require_first_echo || M[0] > 0.0)) {
@@ -232,7 +254,8 @@ struct FitArgs {
     const double *Kd;     // [n][n] dense L^T L
     const double *lam_grid;
     const double *t2s;    // [n]
-    const double *data;   // [nvox][m]
+    const double *data;   // echo e of voxel v at data[v * vs + e * es]
+    int64_t vs, es;
     SortBufs sb;
     double *fsol, *sig, *reg, *lam, *maps;
     int32_t *status;
@@ -413,7 +436,8 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 }
 
 // METHOD: met2_method, or 10 + method for the objective-grid diagnostic.  NB: T2 bins per lane.
-// NB == 1: D and B of the workgroup's flip angle are staged in LDS; NB == 2: read from L2.
+// STAGE = false (default): D, D^T, B of the voxel's flip angle and K are read through L1/L2; STAGE = true (NB == 1 only,
+// MET2_STAGE=1): D and B of the workgroup's flip angle are copied to LDS and the workgroup shares FA-homogeneous chunks.
 // Waves per workgroup the kernel is compiled for: 16 (128 VGPRs) where the method fits that budget without
 // spilling (NNLS, T2SPARC, X2, L-curve), 12 (168 VGPRs) for the two with a second large phase (GCV, BayesReg).
 __host__ __device__ constexpr int method_max_waves(int method) { return (method <= MET2_LCURVE) ? 16 : 12; }
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitA
             const int64_t v = A.sb.perm[first + slot];
 
             // ---- load, normalise by the first echo (motor:129-132), h = D^T b
-            double b = (lane < m) ? A.data[(size_t)v * m + lane] : 0.0;
+            double b = (lane < m) ? A.data[v * A.vs + lane * A.es] : 0.0;
             const double km = bcast(b, 0);
             b = b / km;
             NnlsState<NB> st; st.itmax_hit = 0;
@@ -642,7 +666,8 @@ struct FaArgs {
     int n, m, nfa, np, kmax, waves, wave_doubles;
     const double *Dfa, *Bfa, *Dtfa;
     const double *Kd;         // [n][n], only multiplied by lambda = 0 here (the refactorisation reads its rows)
-    const double *data;
+    const double *data;       // echo e of voxel v at data[v * vs + e * es]
+    int64_t vs, es;
     const uint8_t *mask;
     double *fa_index, *km, *resid;
     int *queue;
@@ -702,7 +727,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             nnls_reset<NB>(st[vv]);
             const int64_t v = v0 + vv;
             const bool in = v < A.nvox;
-            b[vv] = (in && lane < m) ? A.data[(size_t)v * m + lane] : 0.0;
+            b[vv] = (in && lane < m) ? A.data[v * A.vs + lane * A.es] : 0.0;
             double sum = wave_sum(b[vv]);
             bool mk = in && (A.mask ? (A.mask[v] != 0) : true);
             bool fin = (ballot(!isfinite(b[vv])) == 0ull);
@@ -999,7 +1024,8 @@ struct SplineArgs {
     const double *W;          // [nlr][nlr] device: knot slopes = W y
     const double *alpha_hr;   // [nhr] device
     const double *resid;      // [nvox][nlr]
-    const double *data;       // [nvox][nte]
+    const double *data;       // echo e of voxel v at data[v * vs + e * es]
+    int64_t vs, es;
     const uint8_t *mask;
     double *fa_index, *xmin;
     int64_t nvox;
@@ -1023,7 +1049,7 @@ __global__ __launch_bounds__(128) void fa_spline_kernel(SplineArgs A)
     const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (v >= A.nvox) return;
     double sum = 0.0;
-    for (int e = 0; e < A.nte; ++e) sum += A.data[(size_t)v * A.nte + e];
+    for (int e = 0; e < A.nte; ++e) sum += A.data[v * A.vs + e * A.es];
     const bool mk = A.mask ? (A.mask[v] != 0) : true;
     if (!(mk && sum > 0.0)) { A.fa_index[v] = 0.0; if (A.xmin) A.xmin[v] = 0.0; return; }
     double y[MET2_MAX_LR], s[MET2_MAX_LR];
@@ -1082,6 +1108,89 @@ __global__ __launch_bounds__(256) void metrics_kernel(int64_t nvox, int n, const
 #pragma unroll
         for (int b = 0; b < NB; ++b) xs[b] = (lane + 64 * b < n && mk) ? fsol[(size_t)v * n + lane + 64 * b] : 0.0;
         write_metrics<NB>(ml, xs, mk, maps, nvox, v, lane);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// ROI mode (motor/motor_recon_met2_real_data_ROI.py:405-420): per ROI the mean signal over its voxels and the mean
+// EPG kernel (every voxel contributes the dictionary slice of its own flip angle).  Deterministic two-level
+// reduction: a wave per (slice of the voxel list, ROI) accumulates the echoes of its matching voxels in voxel order
+// (lane <-> echo) and a flip-angle histogram; one workgroup per ROI then adds the slices in order and forms
+// mean kernel = sum_fa count[fa] D[fa] / nv.
+// ------------------------------------------------------------------------------------------
+struct RoiArgs {
+    int nte, nt2, nfa, nroi, nslice;
+    int64_t nvox, vs, es;
+    const double *data;
+    const int32_t *roi;        // [nvox] ROI ordinal 0..nroi-1, negative = none
+    const double *fa_index;    // [nvox] or NULL
+    double *part_sig;          // [nroi][nslice][64]
+    int *part_cnt;             // [nroi][nslice][nfa]
+    const double *Dsrc;        // [nfa][nte][nt2]
+    double *Ddst;              // [nroi][nte][nt2]
+    double *mean_sig;          // [nroi][nte]
+    double *count;             // [nroi] voxels per ROI
+    int *err;
+};
+
+__global__ __launch_bounds__(64) void roi_partial_kernel(RoiArgs A)
+{
+    extern __shared__ int roi_hist[];
+    const int lane = lane_id();
+    const int sl = (int)blockIdx.x, r = (int)blockIdx.y;
+    for (int f = lane; f < A.nfa; f += 64) roi_hist[f] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t per = (A.nvox + A.nslice - 1) / A.nslice;
+    const int64_t lo = sl * per, hi = min(A.nvox, lo + per);
+    double acc = 0.0;
+    for (int64_t base = lo; base < hi; base += 64) {
+        const int64_t v = base + lane;
+        u64 hit = ballot(v < hi && A.roi[v] == r);
+        while (hit) {
+            const int bit = first_lane(hit);
+            hit &= hit - 1ull;
+            const int64_t vv = base + bit;
+            if (lane < A.nte) acc += A.data[vv * A.vs + lane * A.es];
+            const int fa = A.fa_index ? (int)A.fa_index[vv] : 0;
+            if (fa < 0 || fa >= A.nfa) { if (lane == 0) atomicOr(A.err, 1); }
+            else if (lane == 0) roi_hist[fa] += 1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    A.part_sig[((size_t)r * A.nslice + sl) * 64 + lane] = acc;
+    for (int f = lane; f < A.nfa; f += 64) A.part_cnt[((size_t)r * A.nslice + sl) * A.nfa + f] = roi_hist[f];
+}
+
+__global__ __launch_bounds__(256) void roi_finish_kernel(RoiArgs A)
+{
+    extern __shared__ int roi_tot[];           // [nfa]
+    __shared__ double s_nv;
+    const int r = (int)blockIdx.x;
+    for (int f = threadIdx.x; f < A.nfa; f += blockDim.x) {
+        int c = 0;
+        for (int sl = 0; sl < A.nslice; ++sl) c += A.part_cnt[((size_t)r * A.nslice + sl) * A.nfa + f];
+        roi_tot[f] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long nv = 0;
+        for (int f = 0; f < A.nfa; ++f) nv += roi_tot[f];
+        s_nv = (double)nv;
+        A.count[r] = (double)nv;
+    }
+    __syncthreads();
+    const double nv = s_nv;
+    if ((int)threadIdx.x < A.nte) {
+        double t = 0.0;
+        for (int sl = 0; sl < A.nslice; ++sl) t += A.part_sig[((size_t)r * A.nslice + sl) * 64 + threadIdx.x];
+        A.mean_sig[(size_t)r * A.nte + threadIdx.x] = t / nv;
+    }
+    const int sz = A.nte * A.nt2;
+    for (int i = threadIdx.x; i < sz; i += blockDim.x) {
+        double t = 0.0;
+        for (int f = 0; f < A.nfa; ++f) { const int c = roi_tot[f]; if (c) t = fma((double)c, A.Dsrc[(size_t)f * sz + i], t); }
+        A.Ddst[(size_t)r * sz + i] = t / nv;
     }
 }
 
@@ -1315,7 +1424,7 @@ extern "C" int met2_smooth_separable(int32_t device, int32_t nx, int32_t ny, int
     if (total == 0) return MET2_OK;
     if (!weights || !data || !out) return fail(MET2_E_INVALID, "NULL argument");
     if (data == out || work == out || work == data) return fail(MET2_E_INVALID, "data, out and work must be distinct");
-    HIPCHK(hipSetDevice(device));
+    USE_DEVICE(device);
     hipStream_t s = (hipStream_t)stream;
     double *tmp = work;
     if (!tmp) HIPCHK(hipMalloc(&tmp, sizeof(double) * (size_t)total));
@@ -1348,7 +1457,7 @@ extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
     if (!data || !out) return fail(MET2_E_INVALID, "NULL argument");
     if (data == out) return fail(MET2_E_INVALID, "NESMA cannot run in place");
     if ((nvox + 3) / 4 > 0x7fffffffLL) return fail(MET2_E_UNSUPPORTED, "volume too large for one launch");
-    HIPCHK(hipSetDevice(device));
+    USE_DEVICE(device);
     hipStream_t s = (hipStream_t)stream;
     NesmaArgs A;
     A.nx = nx; A.ny = ny; A.nz = nz; A.nt = nt; A.data = data; A.mask = mask; A.out = out; A.nvox = nvox;
@@ -1364,16 +1473,16 @@ extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
     return MET2_OK;
 }
 
-extern "C" int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
-                                     int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
-                                     double *fa_index, double *xmin, void *stream)
+extern "C" int met2_fa_spline_select_strided(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
+                                             int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, int64_t voxel_stride,
+                                             int64_t echo_stride, const uint8_t *mask, double *fa_index, double *xmin, void *stream)
 {
     if (!alpha_lr || !resid || !alpha_hr || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
     if (n_lr < 4 || n_lr > MET2_MAX_LR) return fail(MET2_E_UNSUPPORTED, "coarse FA grid must have 4..32 points");
     if (n_hr < 1 || n_te < 1) return fail(MET2_E_INVALID, "bad shape");
     for (int i = 1; i < n_lr; ++i) if (!(alpha_lr[i] > alpha_lr[i - 1])) return fail(MET2_E_INVALID, "coarse FA grid must increase");
     if (nvox <= 0) return MET2_OK;
-    HIPCHK(hipSetDevice(device));
+    USE_DEVICE(device);
     hipStream_t s = (hipStream_t)stream;
     std::vector<double> W;
     spline_weights_host(n_lr, alpha_lr, W);
@@ -1388,12 +1497,19 @@ extern "C" int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr,
     SplineArgs A;
     A.nlr = n_lr; A.nhr = n_hr; A.nte = n_te;
     A.alpha_lr = dbuf; A.W = dbuf + n_lr; A.alpha_hr = dbuf + n_lr + (size_t)n_lr * n_lr;
-    A.resid = resid; A.data = data; A.mask = mask; A.fa_index = fa_index; A.xmin = xmin; A.nvox = nvox;
+    A.resid = resid; A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.mask = mask; A.fa_index = fa_index; A.xmin = xmin; A.nvox = nvox;
     hipLaunchKernelGGL(fa_spline_kernel, dim3((unsigned)((nvox + 127) / 128)), dim3(128), 0, s, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(dbuf));
     return MET2_OK;
+}
+
+extern "C" int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
+                                     int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, const uint8_t *mask,
+                                     double *fa_index, double *xmin, void *stream)
+{
+    return met2_fa_spline_select_strided(device, nvox, n_lr, alpha_lr, resid, n_hr, alpha_hr, n_te, data, n_te, 1, mask, fa_index, xmin, stream);
 }
 
 extern "C" {
@@ -1435,7 +1551,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     if (opt) { memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size); }
     else met2_default_options(&p->opt);
     if (p->opt.device < 0 || p->opt.device >= ndev) { delete p; return fail(MET2_E_INVALID, "device ordinal out of range"); }
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, p->opt.device));
     p->cus = prop.multiProcessorCount;
@@ -1475,7 +1591,7 @@ int met2_plan_get_options(met2_plan *p, met2_options *opt)
 int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
-    (void)hipSetDevice(p->opt.device);
+    DevGuard dev_guard_(p->opt.device);
     void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
     for (void *b : bufs) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1496,7 +1612,7 @@ static int build_gram(met2_plan *p, hipStream_t s)
 int met2_plan_set_t2_grid(met2_plan *p, const double *T2s)
 {
     if (!p || !T2s) return fail(MET2_E_INVALID, "NULL argument");
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     HIPCHK(hipMemcpy(p->dT2, T2s, sizeof(double) * p->n_t2, hipMemcpyHostToDevice));
     p->have_t2 = true;
     return MET2_OK;
@@ -1506,7 +1622,7 @@ int met2_plan_build_dictionary_epg(met2_plan *p, const double *T2s, const double
                                    double TR, void *stream)
 {
     if (!p || !T2s || !T1s || !alpha_deg) return fail(MET2_E_INVALID, "NULL argument");
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     hipStream_t s = (hipStream_t)stream;
     double *tmp = nullptr;
     size_t nb = sizeof(double) * (size_t)(2 * p->n_t2 + p->n_fa);
@@ -1531,7 +1647,7 @@ int met2_plan_build_dictionary_epg(met2_plan *p, const double *T2s, const double
 int met2_plan_set_dictionary(met2_plan *p, const double *dic)
 {
     if (!p || !dic) return fail(MET2_E_INVALID, "NULL argument");
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     size_t nb = sizeof(double) * (size_t)p->n_fa * p->n_te * p->n_t2;
     double *tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, nb));
@@ -1548,7 +1664,7 @@ int met2_plan_get_dictionary(met2_plan *p, double *dic)
 {
     if (!p || !dic) return fail(MET2_E_INVALID, "NULL argument");
     if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     size_t nb = sizeof(double) * (size_t)p->n_fa * p->n_te * p->n_t2;
     double *tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, nb));
@@ -1581,7 +1697,7 @@ int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
         kb[d * 128 + j] = K[(size_t)j * n + c];
         lb[d * 128 + j] = L[(size_t)j * n + c];
     }
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     HIPCHK(hipMemcpy(p->dKband, kb.data(), sizeof(double) * 5 * 128, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->dLband, lb.data(), sizeof(double) * 5 * 128, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->dKd, K.data(), sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
@@ -1633,7 +1749,7 @@ int met2_plan_set_lambda_grid(met2_plan *p, const double *lam, int32_t n)
 {
     if (!p || !lam || n < 3) return fail(MET2_E_INVALID, "bad lambda grid");
     if (n > 64) return fail(MET2_E_UNSUPPORTED, "lambda grid longer than 64 points");
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     if (p->dLam) HIPCHK(hipFree(p->dLam));
     HIPCHK(hipMalloc(&p->dLam, sizeof(double) * n));
     HIPCHK(hipMemcpy(p->dLam, lam, sizeof(double) * n, hipMemcpyHostToDevice));
@@ -1645,6 +1761,15 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
              double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, void *stream)
 {
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    return met2_fit_strided(p, method, nvox, data, p->n_te, 1, fa_index, mask, fsol, sig, reg, lam, maps, status, stream);
+}
+
+int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                     const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
+                     int32_t *status, void *stream)
+{
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    if (voxel_stride == 0 || echo_stride == 0) return fail(MET2_E_INVALID, "zero stride");
     if (nvox == 0) return MET2_OK;                       // empty voxel list: nothing to do (pointers may be NULL)
     if (!data || !fsol || !reg) return fail(MET2_E_INVALID, "NULL argument");
     if (nvox < 0 || nvox > 0x7fffffff) return fail(MET2_E_INVALID, "nvox out of range");
@@ -1656,7 +1781,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     if (method < 0 || method > MET2_BAYESREG) return fail(MET2_E_INVALID, "unknown method");
     if (objgrid && p->nlam > p->n_t2) return fail(MET2_E_UNSUPPORTED, "objective grid longer than n_t2");
     if (nvox == 0) return MET2_OK;
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_sort_bufs(p, nvox);
     if (rc) return rc;
@@ -1694,7 +1819,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     if (const char *e = getenv("MET2_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 1024) chunk = c; }
     const bool dbg = getenv("MET2_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit: nvox=%lld grid=%d block=%d lds=%d\n", (long long)nvox, g.grid, g.block, g.lds); fflush(stderr); }
-    hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, fa_index, mask, 1, sb, status);
+    hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, voxel_stride, echo_stride, fa_index, mask, 1, sb, status);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] classify done\n"); fflush(stderr); }
     hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
@@ -1714,7 +1839,7 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
     A.log_detL = p->log_detL;
     A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
-    A.data = data; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
+    A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }
@@ -1770,10 +1895,18 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
 int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uint8_t *mask, double *fa_index, double *km,
                        double *resid, void *stream)
 {
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    return met2_fa_bruteforce_strided(p, nvox, data, p->n_te, 1, mask, fa_index, km, resid, stream);
+}
+
+int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                               const uint8_t *mask, double *fa_index, double *km, double *resid, void *stream)
+{
     if (!p || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
+    if (voxel_stride == 0 || echo_stride == 0) return fail(MET2_E_INVALID, "zero stride");
     if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
     if (nvox <= 0) return MET2_OK;
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     hipStream_t s = (hipStream_t)stream;
     LaunchGeom g;
     // plain NNLS stops at min(n_t2, n_te) passive bins (Lawson-Hanson's k >= rows test), so the factor needs that
@@ -1793,7 +1926,7 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
     A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
-    A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Kd = p->dKd; A.data = data; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Kd = p->dKd; A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
     HIPCHK(hipEventRecord(p->ev0, s));
 #define MET2_FA_LAUNCH(VPW, NB, WAVES, STG)                                                                              \
@@ -1820,12 +1953,46 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
     return MET2_OK;
 }
 
+int met2_roi_reduce(met2_plan *src, met2_plan *dst, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                    const int32_t *roi_index, const double *fa_index, double *mean_signal, double *count, void *stream)
+{
+    if (!src || !dst || !data || !roi_index || !mean_signal || !count) return fail(MET2_E_INVALID, "NULL argument");
+    if (!src->have_dict) return fail(MET2_E_STATE, "no dictionary in the source plan");
+    if (src->n_te != dst->n_te || src->n_t2 != dst->n_t2) return fail(MET2_E_INVALID, "source and destination plans differ in shape");
+    if (src->opt.device != dst->opt.device) return fail(MET2_E_INVALID, "source and destination plans live on different devices");
+    if (voxel_stride == 0 || echo_stride == 0) return fail(MET2_E_INVALID, "zero stride");
+    if (nvox <= 0) return fail(MET2_E_INVALID, "empty voxel list");
+    USE_DEVICE(src->opt.device);
+    hipStream_t s = (hipStream_t)stream;
+    RoiArgs A;
+    A.nte = src->n_te; A.nt2 = src->n_t2; A.nfa = src->n_fa; A.nroi = dst->n_fa;
+    A.nslice = (int)std::min<int64_t>(256, (nvox + 4095) / 4096);
+    A.nvox = nvox; A.vs = voxel_stride; A.es = echo_stride; A.data = data; A.roi = roi_index; A.fa_index = fa_index;
+    A.Dsrc = src->dD; A.Ddst = dst->dD; A.mean_sig = mean_signal; A.count = count;
+    void *scratch = nullptr;
+    const size_t nsig = sizeof(double) * (size_t)A.nroi * A.nslice * 64, ncnt = sizeof(int) * (size_t)A.nroi * A.nslice * A.nfa;
+    HIPCHK(hipMalloc(&scratch, nsig + ncnt + 16));
+    A.part_sig = (double *)scratch; A.part_cnt = (int *)((char *)scratch + nsig); A.err = (int *)((char *)scratch + nsig + ncnt);
+    HIPCHK(hipMemsetAsync(A.err, 0, sizeof(int), s));
+    hipLaunchKernelGGL(roi_partial_kernel, dim3(A.nslice, A.nroi), dim3(64), sizeof(int) * A.nfa, s, A);
+    hipLaunchKernelGGL(roi_finish_kernel, dim3(A.nroi), dim3(256), sizeof(int) * A.nfa, s, A);
+    HIPCHK(hipGetLastError());
+    int rc = build_gram(dst, s);
+    int herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, A.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(scratch));
+    if (rc) return rc;
+    if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
+    return MET2_OK;
+}
+
 int met2_metrics(met2_plan *p, int64_t nvox, const double *fsol, const uint8_t *mask, double *maps, void *stream)
 {
     if (!p || !fsol || !maps) return fail(MET2_E_INVALID, "NULL argument");
     if (!p->have_t2) return fail(MET2_E_STATE, "no T2 grid set");
     if (nvox <= 0) return MET2_OK;
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     int blocks = (int)((nvox + 3) / 4);
     if (blocks > p->cus * 16) blocks = p->cus * 16;
     if (p->n_t2 <= 64)
@@ -1842,7 +2009,7 @@ int met2_plan_last_kernel_ms(met2_plan *p, double *ms)
 {
     if (!p || !ms) return fail(MET2_E_INVALID, "NULL argument");
     if (!p->timed) return fail(MET2_E_STATE, "no timed launch yet");
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     HIPCHK(hipEventSynchronize(p->ev1));
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, p->ev0, p->ev1));
@@ -1855,7 +2022,7 @@ int met2_plan_last_second_pass_ms(met2_plan *p, double *ms)
     if (!p || !ms) return fail(MET2_E_INVALID, "NULL argument");
     *ms = 0.0;
     if (!p->timed || !p->timed2) return MET2_OK;
-    HIPCHK(hipSetDevice(p->opt.device));
+    USE_DEVICE(p->opt.device);
     HIPCHK(hipEventSynchronize(p->ev2));
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, p->ev1, p->ev2));

@@ -27,10 +27,17 @@ def _chk(*arrs):
 
 def _fit1(method, D, M, L=None, lambda_reg=None, **options):
     plan = plan_for(D, L, lambda_reg)
-    if options:
-        plan.set_options(**options)
     data = torch.as_tensor(M[None, :], device=plan.device)
-    out = plan.fit(method, data, want_maps=False, want_lambda=True)
+    # `factor` / `reg_opt` are per-call arguments in the reference; the cached plan is shared with other callers of the same
+    # (D, L, grid), so its options are put back after the call
+    saved = plan.get_options(*options) if options else {}
+    try:
+        if options:
+            plan.set_options(**options)
+        out = plan.fit(method, data, want_maps=False, want_lambda=True)
+    finally:
+        if saved:
+            plan.set_options(**saved)
     if int(out["status"][0].item()) == 0:
         raise ValueError("signal fails the driver's gates (need M[0] > 0 and sum(M) > 0)")
     return (out["fsol"][0].cpu().numpy(), out["sig"][0].cpu().numpy(), float(out["reg"][0].item()), float(out["lam"][0].item()))

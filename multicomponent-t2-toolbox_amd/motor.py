@@ -1,6 +1,6 @@
 """Drop-ins for motor/motor_recon_met2_real_data.py: create_Laplacian_matrix, fitting_slice_T2, the NESMA filter,
 recon_met2_arrays (the driver's steps 1-4 on in-memory arrays), motor_recon_met2 (the same with the on-disk
-contract) and the ROI mode.  TV denoising (scikit-image), plots and the mean-spectrum PNG are not reproduced."""
+contract) and the ROI mode (recon_met2_rois, motor_recon_met2_ROIs).  Plots and the mean-spectrum PNG are not reproduced."""
 import math
 
 import numpy as np
@@ -107,82 +107,143 @@ def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
     return out.cpu().numpy() if as_numpy else out
 
 
-def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
-                      fa_index=None, device=0, plan=None, denoise="None", prepared=False, FA_smooth="no"):
-    """Steps 1-4 of motor_recon_met2 (motor:293-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
-    [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
-    negative values clipped to 0 (motor:279), optional NESMA filter (motor:305-333, needs a 3-D volume),
-    Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms, T1 = 1000 ms, 91 flip angles for brute force.
-    `prepared=True` says the caller already did that preparation (mask multiply, clip, denoise).
-    FA_smooth='yes' (the CLI default, motor:337-343): the flip angles are estimated on the Gaussian-smoothed volume
-    (sigma = 2 voxels, every echo), the spectra on the unsmoothed one; needs a 3-D volume.
-    Returns a dict with the driver's ten outputs."""
-    if FA_method not in ("brute-force", "spline"):
-        raise ValueError("FA_method must be 'spline' or 'brute-force'")
-    if denoise not in ("None", None, "none", "NESMA"):
-        raise NotImplementedError("denoise=%r is not built: TV (motor:293-304) is scikit-image's estimate_sigma + "
-                                  "denoise_tv_chambolle, a third-party dependency outside the path" % (denoise,))
-    data = np.asarray(data, dtype=np.float64)
-    vol_shape = data.shape[:-1]
-    nt = data.shape[-1]
-    mask = np.asarray(mask).reshape(vol_shape)
-    dev = plan.device if plan is not None else torch.device("cuda", device)
-    # the driver's preparation on the device (the volume goes up once; numpy would spend longer on these two passes
-    # than the GPU on the whole fit)
-    dd = torch.as_tensor(data, device=dev)
+def _prepare_volume(data, mask, dev, prepared, denoise):
+    """The driver's preparation (motor:180-182, :279, :293-333) on the device.  The volume keeps the memory order it
+    arrives in (nibabel arrays are Fortran-ordered; the solver reads either order in place)."""
+    dd = torch.as_tensor(data, dtype=torch.float64, device=dev)
     mk = torch.as_tensor(mask, device=dev)
     if not prepared:
         dd = dd * mk.to(torch.float64).unsqueeze(-1)                # the mask VALUE multiplies (motor:180-182)
         dd = torch.where(dd < 0.0, torch.zeros((), dtype=torch.float64, device=dev), dd)      # motor:279
         if denoise == "NESMA":
-            if len(vol_shape) != 3:
+            if dd.dim() != 4:
                 raise ValueError("NESMA needs data [nx,ny,nz,nt]")
             dd = nesma_filter(dd, mk)
-    dd_fa = None
+        elif denoise == "TV":
+            if dd.dim() != 4:
+                raise ValueError("TV denoising needs data [nx,ny,nz,nt]")
+            from .tv import tv_denoise_volume
+            dd = tv_denoise_volume(dd)
+    return dd, mk
+
+
+def _estimate_fa(plan, dd, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device):
+    """Driver step 2 (motor:349-373) -> flat float64 FA-index tensor in the voxel order of `dd`'s layout."""
+    from .plan import voxel_layout
+    _, nvox, _, _, _, order = voxel_layout(dd, plan.n_te)
+    if fa_index is not None:
+        return plan._per_voxel(np.asarray(fa_index, dtype=np.float64), nvox, torch.float64, "fa_index", order)
+    if FA_method == "spline":
+        alpha_values_spline = np.linspace(90.0, 180.0, 15)                                      # motor:237
+        plan_lr = Met2Plan(plan.n_te, plan.n_t2, 15, device=device)
+        try:
+            plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_values_spline, TR)
+            fa, _, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd_fa, mm, want_km=False)
+        finally:
+            plan_lr.close()
+        return fa
+    fa, _, _ = plan.fa_bruteforce(dd_fa, mm)
+    return fa
+
+
+def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
+                      fa_index=None, device=0, plan=None, denoise="None", prepared=False, FA_smooth="no", distributed=False,
+                      return_prepared=False):
+    """Steps 1-4 of motor_recon_met2 (motor:293-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
+    [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
+    negative values clipped to 0 (motor:279), optional NESMA / TV filter (motor:293-333, needs a 3-D volume),
+    Npc = 60 (96 for T2SPARC, motor:207-213), T2 grid 10..2000 ms, T1 = 1000 ms, 91 flip angles for brute force.
+    `prepared=True` says the caller already did that preparation (mask multiply, clip, denoise).
+    FA_smooth='yes' (the CLI default, motor:337-343): the flip angles are estimated on the Gaussian-smoothed volume
+    (sigma = 2 voxels, every echo), the spectra on the unsmoothed one; needs a 3-D volume.
+    C- and Fortran-ordered volumes (nibabel's) are both read in place.
+    distributed=True (under torch.distributed.run, one rank per GPU): every rank holds the volume, runs the FA step and the
+    fit on its own interleaved 4096-voxel blocks of the voxel list and the outputs meet on rank 0 in ONE gather
+    (dist.fit_sharded); ranks other than 0 return None.
+    Returns a dict with the driver's ten outputs."""
+    if FA_method not in ("brute-force", "spline"):
+        raise ValueError("FA_method must be 'spline' or 'brute-force'")
+    if denoise not in ("None", None, "none", "NESMA", "TV"):
+        raise ValueError("denoise must be 'None', 'NESMA' or 'TV'")
+    data = np.asarray(data, dtype=np.float64)
+    vol_shape = data.shape[:-1]
+    nt = data.shape[-1]
+    mask = np.asarray(mask).reshape(vol_shape)
+    dev = plan.device if plan is not None else torch.device("cuda", device)
+    dd, mk = _prepare_volume(data, mask, dev, prepared, denoise)
+    dd_fa = dd
     if FA_smooth == "yes" and fa_index is None:
         if len(vol_shape) != 3:
             raise ValueError("FA_smooth='yes' needs data [nx,ny,nz,nt]")
-        dd_fa = gaussian_smooth(dd.reshape(vol_shape + (nt,)), 2.0).reshape(-1, nt)
-    dd = dd.reshape(-1, nt).contiguous()
-    if dd_fa is None:
-        dd_fa = dd
-    mm = (mk.reshape(-1) > 0)
+        dd_fa = gaussian_smooth(dd, 2.0)
+    mm = (mk > 0)
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
     Npc = 96 if reg_method == "T2SPARC" else 60
     T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=Npc, endpoint=True, base=10.0)
     T1s = 1000.0 * np.ones_like(T2s)
-    spline = (FA_method == "spline") and fa_index is None
     alpha_values = np.linspace(90.0, 180.0, 91 * 3 if FA_method == "spline" else 91)      # motor:231-244
-    alpha_values_spline = np.linspace(90.0, 180.0, 15)                                      # motor:237
     own = plan is None
-    plan_lr = None
     if own:
         plan = Met2Plan(nt, Npc, alpha_values.shape[0], device=device, myelin_T2=myelin_T2)
         plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
         plan.set_penalty("InvT2" if reg_method == "T2SPARC" else reg_matrix, T2s)   # run_real_data_script.py:91-93
-    if spline:
-        plan_lr = Met2Plan(nt, Npc, 15, device=device)
-        plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_values_spline, TR)
-        fa, km, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd_fa, mm, want_km=False)
-        plan_lr.close()
-    elif fa_index is None:
-        fa, km, _ = plan.fa_bruteforce(dd_fa, mm)
-    else:
-        fa = torch.as_tensor(np.asarray(fa_index, dtype=np.float64).reshape(-1), device=dev)
-    out = plan.fit(reg_method, dd, fa_index=fa, mask=mm)
-    res = {"fsol_4D": out["fsol"].cpu().numpy().reshape(vol_shape + (Npc,)),
-           "Est_Signal": out["sig"].cpu().numpy().reshape(vol_shape + (nt,)),
-           "reg_param": out["reg"].cpu().numpy().reshape(vol_shape),
-           "FA_index": fa.cpu().numpy().reshape(vol_shape)}
-    fitted_fa = (mm & (dd_fa.sum(dim=1) > 0)).cpu().numpy().reshape(vol_shape)      # gate of the FA step (fa_estimation.py:45)
-    res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
-    maps = out["maps"].cpu().numpy()
+    try:
+        if distributed:
+            return _recon_sharded(plan, dd, dd_fa, mm, reg_method, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device, vol_shape)
+        fa = _estimate_fa(plan, dd, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device)
+        out = plan.fit(reg_method, dd, fa_index=fa, mask=mm)
+        from .plan import unflatten, voxel_layout
+        order = voxel_layout(dd, nt)[5]
+        fa_vol = unflatten(fa, vol_shape, order)
+        tot_fa = dd_fa.sum(dim=-1)
+        res = {"fsol_4D": out["fsol"].cpu().numpy(), "Est_Signal": out["sig"].cpu().numpy(), "reg_param": out["reg"].cpu().numpy(),
+               "FA_index": fa_vol.cpu().numpy()}
+        fitted_fa = (mm & (tot_fa > 0)).cpu().numpy()      # gate of the FA step (fa_estimation.py:45)
+        res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
+        maps = out["maps"].cpu().numpy()
+        for i, name in enumerate(MAP_NAMES):
+            res[name] = maps[i]
+        res["T2s"] = T2s
+        if return_prepared:
+            res["data_prepared"] = dd.cpu().numpy()
+        return res
+    finally:
+        if own:
+            plan.close()
+
+
+def _recon_sharded(plan, dd, dd_fa, mm, reg_method, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device, vol_shape):
+    """The multi-GPU leg of recon_met2_arrays: this rank's interleaved blocks through FA estimation + fit, one gather."""
+    from . import dist as mdist
+    from .plan import unflatten_back
+    nt, Npc = plan.n_te, plan.n_t2
+    flat = unflatten_back(dd, "C")                          # [nvox, nt] views in C voxel order (rows are gathered per shard)
+    flat_fa = unflatten_back(dd_fa, "C")
+    mflat = mm.reshape(-1)
+    faflat = None if fa_index is None else torch.as_tensor(np.asarray(fa_index, dtype=np.float64).reshape(-1), device=dd.device)
+
+    def fit_fn(idx):
+        d = flat[idx].contiguous()
+        dfa = d if dd_fa is dd else flat_fa[idx].contiguous()
+        m = mflat[idx]
+        fa = _estimate_fa(plan, d, dfa, m, FA_method, None if faflat is None else faflat[idx].cpu().numpy(), T2s, T1s, tau, TR, alpha_values, device)
+        out = plan.fit(reg_method, d, fa_index=fa, mask=m)
+        out["fa"] = fa
+        out["fa_gate"] = (m & (dfa.sum(dim=1) > 0)).to(torch.float64)
+        return out
+
+    nvox = flat.shape[0]
+    _, full = mdist.fit_sharded(fit_fn, nvox, gather=("fsol", "sig", "reg", "maps", "fa", "fa_gate"))
+    if full is None:
+        return None
+    res = {"fsol_4D": full["fsol"].cpu().numpy().reshape(vol_shape + (Npc,)), "Est_Signal": full["sig"].cpu().numpy().reshape(vol_shape + (nt,)),
+           "reg_param": full["reg"].cpu().numpy().reshape(vol_shape), "FA_index": full["fa"].cpu().numpy().reshape(vol_shape)}
+    res["FA"] = np.where(full["fa_gate"].cpu().numpy().reshape(vol_shape) > 0, alpha_values[res["FA_index"].astype(int)], 0.0)
+    maps = full["maps"].cpu().numpy()
     for i, name in enumerate(MAP_NAMES):
         res[name] = maps[i].reshape(vol_shape)
     res["T2s"] = T2s
-    if own:
-        plan.close()
     return res
 
 
@@ -191,56 +252,117 @@ def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR
     """Drop-in for motor_recon_met2 (motor:165-506) with the reference's on-disk contract: NIfTI in
     (data [nx,ny,nz,nt], mask [nx,ny,nz]), ten NIfTI volumes out (MWF, IEWF, FWF, T2_M, T2_IE, TWC, FA, fsol_4D,
     Est_Signal, reg_param .nii.gz at path_to_save_data, motor:475-503).  `num_cores` is accepted and ignored (one
-    process drives the GPU).  denoise: 'None' or 'NESMA' (motor:305-333).  Not reproduced: TV denoising (motor:293-304,
-    scikit-image) and the mean-spectrum PNG of motor:377-424."""
+    process drives the GPU).  denoise: 'None', 'NESMA' (motor:305-333) or 'TV' (motor:293-304).  Not reproduced: the
+    mean-spectrum PNG of motor:377-424."""
     from . import nifti
-    if denoise not in ("None", None, "none", "NESMA"):
-        raise NotImplementedError("denoise=%r is not built (TV, motor:293-304, is scikit-image code outside the path)" % (denoise,))
     img = nifti.load(path_to_data)
-    data = img.get_fdata().astype(np.float64, copy=False)
+    data = img.get_fdata().astype(np.float64, copy=False)           # Fortran-ordered, like nibabel's: read in place by the solver
     mask = nifti.load(path_to_mask).get_fdata().astype(np.int64)
     if data.ndim != 4 or mask.shape != data.shape[:3]:
         raise ValueError("data must be 4-D and mask must match its first three dimensions")
     res = recon_met2_arrays(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, device=device, denoise=denoise,
-                            FA_smooth=FA_smooth)
+                            FA_smooth=FA_smooth, return_prepared=(denoise == "TV"))
+    if denoise == "TV":                                             # motor:302-303
+        nifti.save(nifti.NiftiImage(res.pop("data_prepared"), img.affine), path_to_save_data + "Data_denoised.nii.gz")
     for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
         nifti.save(nifti.NiftiImage(res[name], img.affine), path_to_save_data + name + ".nii.gz")
     return res
 
 
-def recon_met2_rois(data, rois, fa_index, Dic_3D, T2s, Laplac, factor=1.01, myelin_T2=40.0, device=0):
+def recon_met2_rois(data, rois, fa_index, Dic_3D, T2s, Laplac, factor=1.01, myelin_T2=40.0, device=0, plan=None):
     """ROI-mode estimation (motor/motor_recon_met2_real_data_ROI.py:405-443): for every ROI label > 0 the mean signal and the
     mean EPG kernel over its voxels (each voxel contributes the dictionary slice of its own flip angle), one X2 fit
     (factor 1.01 there) per ROI, then the spectrum metrics.  data [..., nt], rois [...] integer labels, fa_index [...]
-    (indices into Dic_3D's FA axis), Dic_3D [nt, nT2, nFA] (reference layout).
-    Returns dict(labels, fsol [nROI, nT2] normalised to sum 1 like the reference, MWF, IEWF, FWF, T2_M, T2_IE, reg_opt, k_est)."""
-    data = np.asarray(data, dtype=np.float64)
-    nt = data.shape[-1]
-    d2 = data.reshape(-1, nt)
-    lab = np.asarray(rois).reshape(-1)
-    fa = np.asarray(fa_index).reshape(-1).astype(np.int64)
-    D3 = np.asarray(Dic_3D, dtype=np.float64)
-    nT2, nFA = D3.shape[1], D3.shape[2]
-    labels = np.array([v for v in np.unique(lab) if v > 0])
-    if labels.size == 0:
+    (indices into the FA axis of Dic_3D [nt, nT2, nFA], reference layout; or pass `plan`, a Met2Plan that already holds the
+    dictionary).  The reduction runs on the device (met2_roi_reduce, deterministic).  numpy arrays or CUDA tensors.
+    Returns dict(labels, count, fsol [nROI, nT2] normalised to sum 1 like the reference, MWF, IEWF, FWF, T2_M, T2_IE, TWC,
+    reg_opt, k_est, mean_signal)."""
+    from .plan import voxel_layout, _ptr
+    src = plan if plan is not None else plan_for(Dic_3D)
+    dev = src.device
+    dd = torch.as_tensor(data, dtype=torch.float64, device=dev)
+    nt = dd.shape[-1]
+    dd, nvox, vs, es, vol, order = voxel_layout(dd, nt)
+    lab = src._per_voxel(torch.as_tensor(rois, device=dev).to(torch.int64), nvox, torch.int64, "rois", order)
+    fa = src._per_voxel(torch.as_tensor(fa_index, device=dev), nvox, torch.float64, "fa_index", order)
+    labels = torch.unique(lab)
+    labels = labels[labels > 0]
+    nroi = int(labels.numel())
+    if nroi == 0:
         raise ValueError("no ROI label > 0")
-    sig = np.zeros((labels.size, nt))
-    W = np.zeros((labels.size, nFA))
-    for i, v in enumerate(labels):
-        sel = lab == v
-        sig[i] = d2[sel].sum(axis=0) / sel.sum()
-        W[i] = np.bincount(fa[sel], minlength=nFA) / sel.sum()
-    kernels = np.einsum("rf,etf->etr", W, D3)                      # mean kernel per ROI, [nt, nT2, nROI]
-    plan = Met2Plan(nt, nT2, labels.size, device=device, x2_factor=factor, myelin_T2=myelin_T2)
+    pos = torch.searchsorted(labels, lab).clamp(max=nroi - 1)
+    ridx = torch.where(labels[pos] == lab, pos, torch.full_like(pos, -1)).to(torch.int32).contiguous()
+    dst = Met2Plan(nt, src.n_t2, nroi, device=dev.index or 0, x2_factor=factor, myelin_T2=myelin_T2)
     try:
-        plan.set_dictionary(np.ascontiguousarray(kernels)).set_t2_grid(T2s).set_penalty(np.asarray(Laplac, dtype=np.float64))
-        out = plan.fit("X2", torch.as_tensor(sig, device=plan.device),
-                       fa_index=torch.arange(labels.size, dtype=torch.float64, device=plan.device), want_lambda=True)
+        dst.set_t2_grid(T2s).set_penalty(np.asarray(Laplac, dtype=np.float64))
+        sig = torch.empty((nroi, nt), dtype=torch.float64, device=dev)
+        cnt = torch.empty((nroi,), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().met2_roi_reduce(src._h, dst._h, nvox, _ptr(dd), vs, es, _ptr(ridx), _ptr(fa), _ptr(sig), _ptr(cnt), dst._stream()))
+        out = dst.fit("X2", sig, fa_index=torch.arange(nroi, dtype=torch.float64, device=dev), want_lambda=True)
         f = out["fsol"].cpu().numpy()
         maps = out["maps"].cpu().numpy()
-        res = {"labels": labels, "fsol": f / maps[5][:, None], "reg_opt": out["lam"].cpu().numpy(), "k_est": out["reg"].cpu().numpy()}
-        for i, name in enumerate(MAP_NAMES[:5]):
+        res = {"labels": labels.cpu().numpy(), "count": cnt.cpu().numpy(), "fsol": f / maps[5][:, None], "reg_opt": out["lam"].cpu().numpy(),
+               "k_est": out["reg"].cpu().numpy(), "mean_signal": sig.cpu().numpy()}
+        for i, name in enumerate(MAP_NAMES):
             res[name] = maps[i]
         return res
     finally:
+        dst.close()
+
+
+def motor_recon_met2_ROIs(TE_array, path_to_data, path_to_mask, path_to_ROIs, path_to_save_data, TR, reg_matrix, denoise, FA_method,
+                          FA_smooth, myelin_T2, num_cores=-1, device=0):
+    """Drop-in for motor_recon_met2_ROIs (motor/motor_recon_met2_real_data_ROI.py:152-498): NIfTI data, mask and ROI labels in;
+    flip angles per voxel (step 2), then one X2 fit (factor 1.01, :417) per ROI on the ROI's mean signal and mean kernel.
+    Writes the reference's tables: table_MWF.csv, table_Spectra.csv, ROI_labels.csv at path_to_save_data and
+    ROI_<label>/table_values.csv per ROI (:476-498; the PNG plots and the tabulate text table are not reproduced).
+    Labels are taken from the ROI volume before the mask is applied, as the reference does (:175-178); a label that lies
+    entirely outside the mask has no voxels and the reference's nnls_x2 raises ValueError on its nan kernel -- so does this."""
+    import os
+    from . import nifti
+    img = nifti.load(path_to_data)
+    data = img.get_fdata().astype(np.float64, copy=False)
+    mask = nifti.load(path_to_mask).get_fdata().astype(np.int64)
+    rois = nifti.load(path_to_ROIs).get_fdata().astype(np.int64)
+    if data.ndim != 4 or mask.shape != data.shape[:3] or rois.shape != mask.shape:
+        raise ValueError("data must be 4-D; mask and ROIs must match its first three dimensions")
+    if FA_method not in ("brute-force", "spline"):
+        raise ValueError("FA_method must be 'spline' or 'brute-force'")
+    nt = data.shape[-1]
+    labels_all = np.unique(rois)
+    labels_all = labels_all[labels_all != 0]
+    rois = rois * mask                                              # :191
+    dev = torch.device("cuda", device)
+    dd, mk = _prepare_volume(data, mask, dev, False, denoise)
+    dd_fa = gaussian_smooth(dd, 2.0) if FA_smooth == "yes" else dd
+    TE_array = np.asarray(TE_array, dtype=np.float64)
+    tau = float(TE_array[1] - TE_array[0])
+    Npc = 60
+    T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=Npc, endpoint=True, base=10.0)
+    T1s = 1000.0 * np.ones_like(T2s)
+    alpha_values = np.linspace(90.0, 180.0, 91 * 3 if FA_method == "spline" else 91)
+    Laplac = penalty_matrix(reg_matrix, Npc, T2s)
+    plan = Met2Plan(nt, Npc, alpha_values.shape[0], device=device, myelin_T2=myelin_T2)
+    try:
+        plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
+        fa = _estimate_fa(plan, dd, dd_fa, mk > 0, FA_method, None, T2s, T1s, tau, TR, alpha_values, device)
+        from .plan import unflatten, voxel_layout
+        fa_vol = unflatten(fa, data.shape[:3], voxel_layout(dd, nt)[5])
+        present = np.intersect1d(labels_all, np.unique(rois))
+        if present.size != labels_all.size:
+            raise ValueError("array must not contain infs or NaNs")  # a label without voxels inside the mask: 0/0 kernel (see docstring)
+        res = recon_met2_rois(dd, torch.as_tensor(rois, device=dev), fa_vol, None, T2s, Laplac, factor=1.01, myelin_T2=myelin_T2,
+                              device=device, plan=plan)
+    finally:
         plan.close()
+    np.savetxt(path_to_save_data + "table_MWF.csv", res["MWF"], delimiter=",", fmt="%s")
+    np.savetxt(path_to_save_data + "table_Spectra.csv", res["fsol"], delimiter=",", fmt="%s")
+    np.savetxt(path_to_save_data + "ROI_labels.csv", res["labels"], delimiter=",", fmt="%s")
+    for i, lab in enumerate(res["labels"]):
+        d = path_to_save_data + "ROI_%.0f/" % float(lab)
+        os.makedirs(d, exist_ok=True)
+        table = [["1. MWF       ", res["MWF"][i]], ["2. IEWF      ", res["IEWF"][i]], ["3. FWF       ", res["FWF"][i]],
+                 ["4. T2M       ", res["T2_M"][i]], ["5. T2IE      ", res["T2_IE"][i]], ["6. TWC       ", res["TWC"][i]]]
+        np.savetxt(d + "table_values.csv", np.array(table, dtype=object), delimiter=",", fmt="%s")
+    return res

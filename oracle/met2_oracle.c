@@ -792,10 +792,11 @@ MET2O_API void met2o_objective(int method, int m, int n, const double *D, const 
 /* ------------------------------------------------------------------ V1: voxel batch */
 /* motor:113-162 over a flat voxel list.  D is [nfa][nte][nt2]; data [nvox][nte];
  * fa_index as float64 like the reference (cast with (int)), mask float64. */
-MET2O_API int met2o_fit_batch(int method, int nte, int nt2, int nfa, const double *Dfa, const double *L,
+/* lam_out (may be NULL): the selected lambda per voxel (equals reg except for X2, where reg holds k_est) */
+MET2O_API int met2o_fit_batch_lam(int method, int nte, int nt2, int nfa, const double *Dfa, const double *L,
                               const double *lam_grid, int nl, double x2_factor, double t2sparc_lambda,
                               int64_t nvox, const double *data, const double *fa_index, const double *mask,
-                              double *fsol, double *sig, double *reg, int32_t *status, int nthreads)
+                              double *fsol, double *sig, double *reg, double *lam_out, int32_t *status, int nthreads)
 {
     int bad = 0;
 #ifdef _OPENMP
@@ -812,6 +813,7 @@ MET2O_API int met2o_fit_batch(int method, int nte, int nt2, int nfa, const doubl
             double *fo = fsol + (size_t)v * nt2, *so = sig + (size_t)v * nte;
             memset(fo, 0, sizeof(double) * nt2); memset(so, 0, sizeof(double) * nte);
             reg[v] = 0.0; int st = 0;
+            if (lam_out) lam_out[v] = 0.0;
             double sum = 0.0; int finite = 1;
             for (int e = 0; e < nte; ++e) { sum += M[e]; if (!isfinite(M[e])) finite = 0; }
             if (!finite) { st = ST_NONFINITE; if (status) status[v] = st; continue; }
@@ -826,13 +828,14 @@ MET2O_API int met2o_fit_batch(int method, int nte, int nt2, int nfa, const doubl
             switch (method) {
             case M_NNLS: solve_plain(c, f, &rn); r = 0.0; break;
             case M_T2SPARC: solve_aug(c, t2sparc_lambda, f, &rn); r = t2sparc_lambda; break;
-            case M_X2: o_x2(c, x2_factor, f, &r, &k, &st, NULL); r = k; break;   /* motor:141-143 stores k_est */
+            case M_X2: o_x2(c, x2_factor, f, &r, &k, &st, NULL); if (lam_out) lam_out[v] = r; r = k; break;   /* motor:141-143 stores k_est */
             case M_LCURVE: r = o_lcurve(c, lam_grid, nl, NULL, NULL); solve_aug(c, r, f, &rn); break;
             case M_GCV: o_gcv(c, f, &r, &st, NULL); break;
             case M_BAYES: o_bayes(c, f, &r, &st, NULL); break;
             }
             st |= c->mode_or;
             reg[v] = r;
+            if (lam_out && method != M_X2) lam_out[v] = r;
             for (int j = 0; j < nt2; ++j) fo[j] = f[j] * km;
             for (int e = 0; e < nte; ++e) { double t = 0.0; for (int j = 0; j < nt2; ++j) t += D[(size_t)e * nt2 + j] * f[j]; so[e] = t * km; }
             if (status) status[v] = st;
@@ -840,6 +843,15 @@ MET2O_API int met2o_fit_batch(int method, int nte, int nt2, int nfa, const doubl
         free(Mn); free(f); ctx_free(c);
     }
     return bad ? -1 : 0;
+}
+
+MET2O_API int met2o_fit_batch(int method, int nte, int nt2, int nfa, const double *Dfa, const double *L,
+                              const double *lam_grid, int nl, double x2_factor, double t2sparc_lambda,
+                              int64_t nvox, const double *data, const double *fa_index, const double *mask,
+                              double *fsol, double *sig, double *reg, int32_t *status, int nthreads)
+{
+    return met2o_fit_batch_lam(method, nte, nt2, nfa, Dfa, L, lam_grid, nl, x2_factor, t2sparc_lambda, nvox, data, fa_index, mask,
+                               fsol, sig, reg, NULL, status, nthreads);
 }
 
 /* ------------------------------------------------------------------ M1: metrics */

@@ -151,7 +151,8 @@ def fminbound_poly(c, r, p, x1, x2, xatol=1e-5, maxfun=300, cap=400):
 
 
 # ------------------------------------------------------------------ batches
-def fit_batch(method, D_fa_major, L, data, fa_index, mask, lambda_reg=None, x2_factor=1.02, t2sparc_lambda=1.8, nthreads=1):
+def fit_batch(method, D_fa_major, L, data, fa_index, mask, lambda_reg=None, x2_factor=1.02, t2sparc_lambda=1.8, nthreads=1,
+              want_lambda=False):
     D = _d(D_fa_major)
     nfa, nte, nt2 = D.shape
     data = _d(data); nvox = data.shape[0]
@@ -160,12 +161,13 @@ def fit_batch(method, D_fa_major, L, data, fa_index, mask, lambda_reg=None, x2_f
     lg = _d(lambda_reg) if lambda_reg is not None else np.zeros(1)
     fsol = np.zeros((nvox, nt2)); sig = np.zeros((nvox, nte)); reg = np.zeros(nvox)
     status = np.zeros(nvox, dtype=np.int32)
-    rc = lib().met2o_fit_batch(METHODS[method], nte, nt2, nfa, _p(D), _p(L), _p(lg), lg.shape[0], C.c_double(x2_factor),
-                               C.c_double(t2sparc_lambda), C.c_int64(nvox), _p(data), _p(fa), _p(mk), _p(fsol), _p(sig), _p(reg),
-                               status.ctypes.data_as(_ip), int(nthreads))
+    lam = np.zeros(nvox)
+    rc = lib().met2o_fit_batch_lam(METHODS[method], nte, nt2, nfa, _p(D), _p(L), _p(lg), lg.shape[0], C.c_double(x2_factor),
+                                   C.c_double(t2sparc_lambda), C.c_int64(nvox), _p(data), _p(fa), _p(mk), _p(fsol), _p(sig), _p(reg),
+                                   _p(lam), status.ctypes.data_as(_ip), int(nthreads))
     if rc != 0:
         raise IndexError("FA index outside the dictionary")
-    return fsol, sig, reg, status
+    return (fsol, sig, reg, status, lam) if want_lambda else (fsol, sig, reg, status)
 
 
 def fitting_slice_T2(mask_1d, data_1d, FA_index_1d, nx, Dic_3D, lambda_reg, T2dim, nEchoes, reg_method, Laplac, dist_x_prior=None):

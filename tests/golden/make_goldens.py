@@ -128,6 +128,7 @@ def synth_voxels(rng, nvox, nte, epg_signal, fa_deg=None, snr_lo=50.0, snr_hi=15
     rad = np.pi / 180.0
     data = np.zeros((nvox, nte))
     fa_true = np.zeros(nvox)
+    cache = {}
     for v in range(nvox):
         MWF = rng.uniform(0.05, 0.25)
         T2m = rng.uniform(15.0, 35.0)
@@ -138,7 +139,11 @@ def synth_voxels(rng, nvox, nte, epg_signal, fa_deg=None, snr_lo=50.0, snr_hi=15
         sie = rng.uniform(6.0, 12.0)
         dist = MWF * norm.pdf(T2grid, T2m, sm) + (1.0 - MWF) * norm.pdf(T2grid, T2ie, sie)
         dist = dist / np.sum(dist)
-        sig_all = (1.0 - np.exp(-TR / T1grid)) * epg_signal(nte, te, 1.0 / T1grid, 1.0 / T2grid, FA * rad, FA / 2.0 * rad)
+        if FA not in cache:                  # same values as a fresh call; a constant flip angle is evaluated once
+            if len(cache) > 4:
+                cache.clear()
+            cache[FA] = (1.0 - np.exp(-TR / T1grid)) * epg_signal(nte, te, 1.0 / T1grid, 1.0 / T2grid, FA * rad, FA / 2.0 * rad)
+        sig_all = cache[FA]
         S = np.sum(1000.0 * sig_all * dist, axis=1)
         if np.isfinite(SNR):
             s = S[0] / SNR
@@ -460,9 +465,156 @@ def gen_smooth(seed):
     print("wrote golden_motor_default_smooth.npz", sm.shape, float(np.abs(sm - data * mask[..., None]).max()))
 
 
+def gen_roi(seed):
+    """The ROI-mode driver (motor/motor_recon_met2_real_data_ROI.py:152-498) on a small in-memory volume with three ROI labels
+    (one of them partly outside the mask).  joypy (absent) is replaced by a stub that draws nothing; `np.int` (removed from
+    numpy 1.24) is aliased to int; the tables the driver writes with np.savetxt are recorded."""
+    from epg.epg import epg_signal
+    import matplotlib
+    import matplotlib.pyplot as plt
+    matplotlib.rcParams["text.usetex"] = False
+    if "joypy" not in sys.modules:
+        jp = types.ModuleType("joypy")
+        jp.joyplot = lambda *a, **k: (plt.figure(), None)
+        sys.modules["joypy"] = jp
+    if not hasattr(np, "int"):
+        np.int = int
+    import motor.motor_recon_met2_real_data_ROI as roi_mod
+    rng = np.random.default_rng(seed)
+    nx, ny, nz, nte = 6, 5, 3, 32
+    data, _ = synth_voxels(rng, nx * ny * nz, nte, epg_signal, fa_deg=None)
+    data = data.reshape(nx, ny, nz, nte)
+    mask = np.ones((nx, ny, nz)); mask[0, 0, :] = 0; mask[5, 4, 2] = 0
+    rois = np.zeros((nx, ny, nz))
+    rois[0:3, :, :] = 3            # label 3 includes masked-out voxels (0,0,:)
+    rois[3:5, 0:3, :] = 7
+    rois[5, :, 0:2] = 12
+    _NIB_FILES["roi_data"] = data
+    _NIB_FILES["roi_mask"] = mask
+    _NIB_FILES["roi_rois"] = rois
+    saved = {}
+    orig_savetxt = np.savetxt
+
+    def spy_savetxt(fname, X, *a, **k):
+        saved[str(fname)] = np.array(X, dtype=object)
+        return orig_savetxt(fname, X, *a, **k)
+
+    TE = 10.0 * np.arange(1, nte + 1)
+    os.makedirs("/tmp/met2_golden_png/roi", exist_ok=True)
+    prefix = "/tmp/met2_golden_png/roi/"
+    fa_rows = {}
+    orig_fa = roi_mod.fitting_slice_FA_brute_force
+    state = {"z": -1, "y": 0}
+
+    def spy_fa(mask_1d, data_1d, nx_, Dic_3D, alpha_values):
+        if state["y"] == 0:
+            state["z"] += 1
+        r = orig_fa(mask_1d, data_1d, nx_, Dic_3D, alpha_values)
+        fa_rows[(state["y"], state["z"])] = np.array(r[1])
+        state["y"] = (state["y"] + 1) % ny
+        return r
+
+    np.savetxt = spy_savetxt
+    roi_mod.fitting_slice_FA_brute_force = spy_fa
+    try:
+        with np.errstate(all="ignore"):
+            roi_mod.motor_recon_met2_ROIs(TE, "roi_data", "roi_mask", "roi_rois", prefix, 3000.0, "L2", "None", "brute-force", "no", 40.0, 1)
+    finally:
+        np.savetxt = orig_savetxt
+        roi_mod.fitting_slice_FA_brute_force = orig_fa
+    fa_index = np.zeros((nx, ny, nz))
+    for (y, z), r in fa_rows.items():
+        fa_index[:, y, z] = r
+    out = {"data": data, "mask": mask, "rois": rois, "TE": TE, "FA_index": fa_index,
+           "table_MWF": saved[prefix + "table_MWF.csv"].astype(np.float64),
+           "table_Spectra": saved[prefix + "table_Spectra.csv"].astype(np.float64),
+           "ROI_labels": saved[prefix + "ROI_labels.csv"].astype(np.float64)}
+    for lab in out["ROI_labels"]:
+        tv = saved[prefix + "ROI_%.0f/table_values.csv" % lab]
+        out["values_%d" % int(lab)] = np.array([float(v) for v in tv[:, 1]])
+    np.savez_compressed(os.path.join(HERE, "golden_roi.npz"), **out)
+    print("wrote golden_roi.npz", out["ROI_labels"], out["table_MWF"])
+
+
+# --------------------------------------------------------------------------- large "tail" fixtures
+_TAIL = {}
+
+
+def _tail_worker(args):
+    """One chunk of voxels through the reference's own functions (runs in a forked worker)."""
+    lo, hi = args
+    import intravoxel_algorithms.algorithms as alg
+    import intravoxel_algorithms.bayesian_interpolation as bay
+    D, M, pens, lam_grid, methods = _TAIL["D"], _TAIL["M"], _TAIL["pens"], _TAIL["lam_grid"], _TAIL["methods"]
+    npc = D.shape[1]
+    res = {}
+    for meth, pen, nmax in methods:
+        L = pens[pen]
+        a, b = lo, min(hi, nmax)
+        n = max(0, b - a)
+        f = np.zeros((n, npc)); lam = np.zeros(n); aux = np.zeros(n)
+        for i in range(n):
+            v = a + i
+            with np.errstate(all="ignore"):
+                if meth == "NNLS":
+                    f[i], aux[i] = alg.nnls(D, M[v])
+                elif meth == "X2":
+                    f[i], lam[i], aux[i] = alg.nnls_x2(D, M[v], L, 1.02)
+                elif meth == "L_curve":
+                    lam[i] = alg.nnls_lcurve_wrapper(D, M[v], L, lam_grid)
+                    f[i] = alg.nnls_tik(D, M[v], L, lam[i])
+                elif meth == "GCV":
+                    f[i], lam[i] = alg.nnls_gcv(D, M[v], L)
+                elif meth == "BayesReg":
+                    f[i], lam[i] = bay.BayesReg_nnls(D, M[v], L)
+        res[(meth, pen)] = (a, f, lam, aux)
+    return res
+
+
+def gen_tail(tag, nte, npc, nvox, methods, seed, procs=7, chunk=32):
+    """A few thousand voxels through the reference for the methods whose parity has a tail (X2: Brent ties;
+    BayesReg/InvT2: flat evidence minimum; GCV: staircase objective), so that rates of 1e-4 are visible.
+    Same recipe and dictionary (FA 150) as gen_shape; data normalised by the first echo as fitting_slice_T2 does."""
+    import multiprocessing as mp
+    from epg.epg import create_Dic_3D, epg_signal
+    from motor.motor_recon_met2_real_data import create_Laplacian_matrix
+
+    rng = np.random.default_rng(seed)
+    T2s = t2_grid(npc)
+    T1s = 1000.0 * np.ones_like(T2s)
+    TR, te = 3000.0, 10.0
+    D = np.ascontiguousarray(create_Dic_3D(npc, T2s, T1s, nte, te, np.array([150.0]), TR)[:, :, 0])
+    data, _ = synth_voxels(rng, nvox, nte, epg_signal, fa_deg=150.0)
+    M = data / data[:, :1]
+    pens = penalties(npc, T2s, create_Laplacian_matrix)
+    _TAIL.update(D=D, M=M, pens=pens, lam_grid=lambda_grid(), methods=methods)
+    jobs = [(lo, min(nvox, lo + chunk)) for lo in range(0, nvox, chunk)]
+    out = {"T2s": T2s, "T1s": T1s, "TR": TR, "tau": te, "nte": nte, "npc": npc, "D150": D, "data": data,
+           "lambda_grid": lambda_grid()}
+    acc = {}
+    for meth, pen, nmax in methods:
+        acc[(meth, pen)] = (np.zeros((nmax, npc)), np.zeros(nmax), np.zeros(nmax))
+    with mp.get_context("fork").Pool(procs) as pool:
+        for k, res in enumerate(pool.imap_unordered(_tail_worker, jobs)):
+            for key, (a, f, lam, aux) in res.items():
+                F, Lm, A = acc[key]
+                F[a:a + f.shape[0]] = f; Lm[a:a + f.shape[0]] = lam; A[a:a + f.shape[0]] = aux
+            if k % 16 == 0:
+                print("  tail %s: chunk %d / %d" % (tag, k + 1, len(jobs)), flush=True)
+    for (meth, pen), (F, Lm, A) in acc.items():
+        base = "%s_%s" % (meth, pen)
+        out[base + "_f"] = F
+        if meth != "NNLS":
+            out[base + "_lam"] = Lm
+        if meth in ("X2", "NNLS"):
+            out[base + "_aux"] = A            # k_est (X2) / residual norm (NNLS)
+    np.savez_compressed(os.path.join(HERE, "golden_tail_%s.npz" % tag), **out)
+    print("wrote golden_tail_%s.npz (%d arrays)" % (tag, len(out)))
+
+
 def main():
     install_shims()
-    which = sys.argv[1:] or ["S1", "S2", "motor", "nesma", "smooth"]
+    which = sys.argv[1:] or ["S1", "S2", "motor", "nesma", "smooth", "roi"]
     if "S1" in which:
         gen_shape("S1", 32, 60, nvox=32, nvox_slow=32, seed=20260101, with_fa_full=True)
     if "S2" in which:
@@ -474,6 +626,15 @@ def main():
         gen_nesma(20260113)
     if "smooth" in which:
         gen_smooth(20260114)
+    if "roi" in which:
+        gen_roi(20260115)
+    # not in the default list: ~15 minutes on 7 processes
+    if "tailS1" in which:
+        gen_tail("S1", 32, 60, 4096, [("NNLS", "I", 4096), ("X2", "L2", 4096), ("X2", "I", 1024), ("L_curve", "L1", 4096),
+                                      ("BayesReg", "InvT2", 4096), ("BayesReg", "I", 1024), ("GCV", "L2", 4096)], 20260121)
+    if "tailS2" in which:
+        gen_tail("S2", 48, 120, 512, [("X2", "L2", 512), ("L_curve", "L1", 512), ("BayesReg", "InvT2", 512), ("GCV", "L2", 512)],
+                 20260122)
 
 
 if __name__ == "__main__":

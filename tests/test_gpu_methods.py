@@ -242,9 +242,18 @@ def test_file_level_driver_on_disk_contract(pkg, tmp_path):
             assert np.allclose(got, g[name], rtol=1e-4, atol=1e-12)
         else:
             assert np.max(np.abs(got - g[name])) / max(1.0, np.max(np.abs(g[name]))) < TOL, name
-    with pytest.raises(NotImplementedError):
-        motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "TV",
+    with pytest.raises(ValueError):
+        motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "wavelet",
                                "brute-force", "no", 40.0, 1)
+    # denoise='TV' (motor:293-304; parity unpinned, see tv.py): runs, writes Data_denoised.nii.gz like the reference, and the
+    # denoised volume has a smaller total variation than the input
+    res_tv = motor.motor_recon_met2(g["TE"], str(tmp_path / "data.nii.gz"), str(tmp_path / "mask.nii.gz"), out, 3000.0, "X2", "L2", "TV",
+                                    "brute-force", "no", 40.0, 1)
+    den = nifti.load(out + "Data_denoised.nii.gz").get_fdata()
+    src = g["data"] * g["mask"][..., None]
+    tvn = lambda a: sum(np.abs(np.diff(a, axis=ax)).sum() for ax in range(3))
+    assert den.shape == src.shape and np.isfinite(den).all() and tvn(den) < tvn(src)
+    assert np.isfinite(res_tv["MWF"]).all()
 
 
 def test_nesma_filter_and_driver_golden(pkg, tmp_path):

@@ -1,0 +1,274 @@
+"""GPU tests of the round-2 boundary work: strided (Fortran-ordered) input read in place, the ROI mode reduced on the
+device and pinned to the reference's own ROI driver, the multi-GPU path with the HIP fit as compute (two ranks sharing
+cuda:0 over gloo), and the sharded volume driver."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, relmax, relmax_rows
+
+pytestmark = pytest.mark.gpu
+
+PKG = "multicomponent-t2-toolbox_amd"
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available()
+    return importlib.import_module(PKG)
+
+
+def _plan(pkg, nfa_grid, pen="L2", nte=32, nt2=60):
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(nt2)
+    plan = pkg.Met2Plan(nte, nt2, len(nfa_grid))
+    plan.build_dictionary_epg(T2s, 1000.0 * np.ones(nt2), 10.0, np.asarray(nfa_grid, dtype=np.float64), 3000.0).set_penalty(pen, T2s)
+    return plan
+
+
+@pytest.mark.parametrize("meth", ["X2", "NNLS"])
+def test_fortran_ordered_volume_is_read_in_place(pkg, meth):
+    # SURVEY.md section 8b(2) "data (+strides)": nibabel hands the driver Fortran-ordered arrays (motor:167-173).  The strided
+    # entry reads them without a transposed copy and returns the same bits as the contiguous call.
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    alphas = np.linspace(90.0, 180.0, 91)
+    plan = _plan(pkg, alphas)
+    nx, ny, nz, nte = 7, 5, 3, 32
+    data, fa, _ = synth.make_voxels(nx * ny * nz, nte=nte, seed=77, fa_values=alphas, device="cuda")
+    vol_c = data.reshape(nx, ny, nz, nte).clone()
+    vol_c[1, 1, 1, :] = 0.0                                          # a gated-out voxel
+    fa_c = fa.reshape(nx, ny, nz)
+    mask = torch.ones((nx, ny, nz), device="cuda"); mask[0, 0, 0] = 0
+    # Fortran-ordered copy of the same volume: strides (1, nx, nx*ny, nx*ny*nz) elements
+    vol_f = torch.empty_strided((nx, ny, nz, nte), (1, nx, nx * ny, nx * ny * nz), dtype=torch.float64, device="cuda")
+    vol_f.copy_(vol_c)
+    assert not vol_f.is_contiguous() and torch.equal(vol_f, vol_c)
+    ptr_before = vol_f.data_ptr()
+    oc = plan.fit(meth, vol_c, fa_index=fa_c, mask=mask, want_lambda=True)
+    of = plan.fit(meth, vol_f, fa_index=fa_c, mask=mask, want_lambda=True)
+    assert vol_f.data_ptr() == ptr_before
+    for k in ("fsol", "sig", "reg", "lam", "maps", "status"):
+        assert oc[k].shape == of[k].shape, k
+        assert torch.equal(oc[k], of[k]), k
+    assert oc["fsol"].shape == (nx, ny, nz, 60) and oc["maps"].shape == (6, nx, ny, nz)
+    assert not oc["fsol"][1, 1, 1].any() and not oc["fsol"][0, 0, 0].any() and int(oc["status"][1, 1, 1]) == 0
+    # flat list == volume
+    flat = plan.fit(meth, vol_c.reshape(-1, nte), fa_index=fa_c.reshape(-1), mask=mask.reshape(-1))
+    assert torch.equal(flat["fsol"].reshape(nx, ny, nz, 60), oc["fsol"])
+    # brute-force FA on both layouts
+    fa1, km1, _ = plan.fa_bruteforce(vol_c, mask)
+    fa2, km2, _ = plan.fa_bruteforce(vol_f, mask)
+    plan_mod = importlib.import_module(PKG + ".plan")
+    assert torch.equal(plan_mod.unflatten(fa1, (nx, ny, nz), "C"), plan_mod.unflatten(fa2, (nx, ny, nz), "F"))
+    assert torch.equal(plan_mod.unflatten(km1, (nx, ny, nz), "C"), plan_mod.unflatten(km2, (nx, ny, nz), "F"))
+    plan.close()
+
+
+def test_strided_entry_through_raw_ctypes(pkg):
+    # the C ABI itself, no Python mirror in between: echo-major [nte][nvox] buffer against voxel-major [nvox][nte]
+    import torch
+    lib = importlib.import_module(PKG + "._lib").lib()
+    synth = importlib.import_module(PKG + ".synth")
+    plan = _plan(pkg, [150.0])
+    nvox, nte, nt2 = 300, 32, 60
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=78, device="cuda")
+    echo_major = data.t().contiguous()                               # [nte][nvox]
+
+    def run(ptr, vs, es):
+        fsol = torch.empty((nvox, nt2), dtype=torch.float64, device="cuda")
+        reg = torch.empty((nvox,), dtype=torch.float64, device="cuda")
+        rc = lib.met2_fit_strided(plan._h, 2, nvox, C.c_void_p(ptr), vs, es, None, None, C.c_void_p(fsol.data_ptr()), None,
+                                  C.c_void_p(reg.data_ptr()), None, None, None, None)
+        assert rc == 0, lib.met2_last_error()
+        torch.cuda.synchronize()
+        return fsol, reg
+
+    f1, r1 = run(data.data_ptr(), nte, 1)
+    f2, r2 = run(echo_major.data_ptr(), 1, nvox)
+    assert torch.equal(f1, f2) and torch.equal(r1, r2)
+    assert lib.met2_fit_strided(plan._h, 2, nvox, C.c_void_p(data.data_ptr()), 0, 1, None, None, C.c_void_p(f1.data_ptr()), None,
+                                C.c_void_p(r1.data_ptr()), None, None, None, None) != 0          # zero stride is refused
+    plan.close()
+
+
+def test_input_validation_raises_instead_of_reading_out_of_bounds(pkg):
+    import torch
+    plan = _plan(pkg, [150.0])
+    good = torch.rand((10, 32), dtype=torch.float64, device="cuda") + 0.5
+    with pytest.raises(ValueError):
+        plan.fit("X2", good[:, :31])                                 # wrong echo count
+    with pytest.raises(ValueError):
+        plan.fit("X2", good.float())                                 # wrong dtype
+    with pytest.raises(ValueError):
+        plan.fit("X2", good.cpu())                                   # host tensor
+    with pytest.raises(ValueError):
+        plan.fit("X2", good, fa_index=torch.zeros(9, device="cuda")) # per-voxel array of the wrong length
+    with pytest.raises(ValueError):
+        plan.fit("X2", good, out={"fsol": torch.empty((9, 60), dtype=torch.float64, device="cuda")})
+    with pytest.raises(ValueError):
+        plan.fit("nope", good)
+    with pytest.raises(ValueError):
+        plan.fa_bruteforce(good[:, :5])
+    # the L-curve grid survives a diagnostic objective-grid call
+    before = plan.fit("L_curve", good, want_lambda=True)["lam"].clone()
+    plan.objective_grid("X2", good, np.array([1e-3, 1e-2, 1e-1]))
+    after = plan.fit("L_curve", good, want_lambda=True)["lam"]
+    assert torch.equal(before, after)
+    plan.close()
+
+
+def test_cached_plan_options_are_not_leaked_between_calls(pkg, gS1):
+    # nnls_x2(..., factor) / nnls_tik(..., reg_opt) set options on a shared cached plan
+    ia = importlib.import_module(PKG + ".intravoxel_algorithms")
+    cache = importlib.import_module(PKG + "._cache")
+    g = gS1
+    D = g["D150"]; M = g["data"][0] / g["data"][0, 0]; L = g["L_L2"]
+    f_ref, lam_ref, k_ref = ia.nnls_x2(D, M, L, 1.02)
+    ia.nnls_x2(D, M, L, 1.10)
+    plan = cache.plan_for(D, L, None)
+    assert abs(plan.get_options("x2_factor")["x2_factor"] - 1.02) < 1e-15
+    f2, lam2, k2 = ia.nnls_x2(D, M, L, 1.02)
+    assert np.array_equal(f_ref, f2) and lam_ref == lam2
+    ia.nnls_tik(D, M, L, 0.5)
+    assert abs(plan.get_options("t2sparc_lambda")["t2sparc_lambda"] - 1.8) < 1e-15
+    # LRU: a plan that is still in use is never closed by an eviction
+    held = cache.plan_for(D, L, None)
+    for i in range(10):
+        cache.plan_for(D * (1.0 + 0.01 * (i + 1)), L, None)
+    f3, _, _ = ia.nnls_x2(D, M, L, 1.02)
+    assert held._h is not None and np.array_equal(f_ref, f3)
+    cache.clear()
+
+
+def test_roi_mode_against_the_reference_roi_driver(pkg, tmp_path):
+    # motor/motor_recon_met2_real_data_ROI.py:152-498 run by tests/golden/make_goldens.py gen_roi: same volume through the
+    # on-disk drop-in; labels, spectra, MWF and the per-ROI table must match what the reference wrote
+    motor = importlib.import_module(PKG + ".motor")
+    nifti = importlib.import_module(PKG + ".nifti")
+    g = np.load(os.path.join(GOLDEN, "golden_roi.npz"))
+    d = str(tmp_path) + "/"
+    nifti.save(nifti.NiftiImage(g["data"], np.eye(4)), d + "data.nii.gz")
+    nifti.save(nifti.NiftiImage(g["mask"].astype(np.int16), np.eye(4)), d + "mask.nii.gz")
+    nifti.save(nifti.NiftiImage(g["rois"].astype(np.int16), np.eye(4)), d + "rois.nii.gz")
+    res = motor.motor_recon_met2_ROIs(g["TE"], d + "data.nii.gz", d + "mask.nii.gz", d + "rois.nii.gz", d + "out_", 3000.0, "L2", "None",
+                                      "brute-force", "no", 40.0, 1)
+    assert np.array_equal(res["labels"], g["ROI_labels"].astype(np.int64))
+    assert np.max(relmax_rows(res["fsol"], g["table_Spectra"])) < TOL
+    assert np.max(np.abs(res["MWF"] - g["table_MWF"])) < TOL
+    for i, lab in enumerate(res["labels"]):
+        ref = g["values_%d" % int(lab)]                              # fM, fIE, fCSF, T2m, T2IE, vt
+        got = np.array([res[k][i] for k in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC")])
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-5), (lab, got, ref)
+    # files written with the reference's names
+    assert np.allclose(np.loadtxt(d + "out_table_MWF.csv", delimiter=","), g["table_MWF"], atol=TOL)
+    assert np.loadtxt(d + "out_table_Spectra.csv", delimiter=",").shape == g["table_Spectra"].shape
+    assert os.path.exists(d + "out_ROI_3/table_values.csv")
+    # label 3 covers (0,0,:) which the mask removes: 87 of 90 voxels
+    assert res["count"].tolist() == [float(((g["rois"] * g["mask"]) == v).sum()) for v in res["labels"]]
+
+
+def test_roi_reduction_on_device_vs_host_sums(pkg):
+    # met2_roi_reduce: mean signal and mean kernel per ROI, C- and Fortran-ordered volumes, labels that are not 1..n
+    import torch
+    motor = importlib.import_module(PKG + ".motor")
+    synth = importlib.import_module(PKG + ".synth")
+    from oracle import oracle
+    T2s = synth.t2_grid(60); T1s = 1000.0 * np.ones(60); alphas = np.linspace(90.0, 180.0, 91)
+    Dic = importlib.import_module(PKG + ".epg").create_Dic_3D(60, T2s, T1s, 32, 10.0, alphas, 3000.0)
+    nx, ny, nz = 9, 8, 7
+    data, fa, _ = synth.make_voxels(nx * ny * nz, nte=32, seed=51, fa_values=alphas, device="cuda")
+    vol = data.reshape(nx, ny, nz, 32)
+    rng = np.random.default_rng(2)
+    rois = rng.choice(np.array([0, 2, 5, 11, 40]), size=(nx, ny, nz))
+    L = motor.create_Laplacian_matrix(60, 2)
+    res = motor.recon_met2_rois(vol, rois, fa.reshape(nx, ny, nz), Dic, T2s, L)
+    vol_f = torch.empty_strided(vol.shape, (1, nx, nx * ny, nx * ny * nz), dtype=torch.float64, device="cuda"); vol_f.copy_(vol)
+    res_f = motor.recon_met2_rois(vol_f, rois, fa.reshape(nx, ny, nz), Dic, T2s, L)
+    assert list(res["labels"]) == [2, 5, 11, 40]
+    d2 = data.cpu().numpy(); fan = fa.cpu().numpy().astype(int); lab = rois.reshape(-1)
+    for i, v in enumerate(res["labels"]):
+        sel = lab == v
+        ts = d2[sel].sum(axis=0) / sel.sum()
+        assert relmax(res["mean_signal"][i], ts) < 1e-13 and res["count"][i] == sel.sum()
+        tk = sum(Dic[:, :, k] for k in fan[sel]) / sel.sum()
+        x, lam, kest = oracle.nnls_x2(tk, ts, L, 1.01)
+        xs = x / (x.sum() + 1e-16)
+        assert relmax(res["fsol"][i], xs) < TOL
+        assert abs(res["reg_opt"][i] - lam) < 1e-5 * max(lam, 1e-3) and abs(res["k_est"][i] - kest) < 1e-6
+        assert abs(res["MWF"][i] - xs[T2s <= 40.0].sum()) < TOL
+    # the Fortran-ordered volume visits the voxels in another order: sums agree to rounding, spectra to tolerance
+    assert relmax(res_f["mean_signal"], res["mean_signal"]) < 1e-13
+    assert np.max(relmax_rows(res_f["fsol"], res["fsol"])) < TOL
+    with pytest.raises(ValueError):
+        motor.recon_met2_rois(vol, np.zeros((nx, ny, nz), dtype=int), fa.reshape(nx, ny, nz), Dic, T2s, L)
+
+
+_SHARED_GPU_WORKER = r"""
+import os, sys, importlib
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+pkg = importlib.import_module(%(pkg)r)
+d = importlib.import_module(%(pkg)r + ".dist")
+synth = importlib.import_module(%(pkg)r + ".synth")
+motor = importlib.import_module(%(pkg)r + ".motor")
+rank, local, world = d.init(backend="gloo")              # both ranks drive cuda:0; the collective moves host copies
+torch.cuda.set_device(0)
+nvox, nte, nt2 = 10007, 32, 60                           # not a multiple of the block size or of the world size
+alphas = np.linspace(90.0, 180.0, 91)
+T2s = synth.t2_grid(nt2)
+plan = pkg.Met2Plan(nte, nt2, 91, device=0)
+plan.build_dictionary_epg(T2s, 1000.0 * np.ones(nt2), 10.0, alphas, 3000.0).set_penalty("L2", T2s)
+data, fa, _ = synth.make_voxels(nvox, nte=nte, seed=99, fa_values=alphas, device="cuda:0")
+calls = {"n": 0}
+og = dist.gather
+def counting(*a, **k):
+    calls["n"] += 1
+    return og(*a, **k)
+dist.gather = counting
+def fit_fn(idx):                                         # the PRODUCT compute: HIP fit through the C ABI
+    return plan.fit("X2", data[idx].contiguous(), fa_index=fa[idx], want_lambda=True)
+out, full = d.fit_sharded(fit_fn, nvox, gather=("maps", "reg", "lam", "fsol"), block=1024)
+assert calls["n"] == 1, calls
+if rank == 0:
+    one = plan.fit("X2", data, fa_index=fa, want_lambda=True)
+    for k in ("maps", "reg", "lam", "fsol"):
+        assert torch.equal(full[k].cuda(), one[k]), k
+    print("SHARED_GPU_OK", world, int(d.shard_count(nvox, 0, world, 1024)), int(d.shard_count(nvox, 1, world, 1024)))
+else:
+    assert full is None
+# the volume driver in its distributed mode
+vol = data[:8 * 9 * 10].reshape(8, 9, 10, nte).cpu().numpy()
+mask = np.ones((8, 9, 10)); mask[0, 0, 0] = 0
+TE = 10.0 * np.arange(1, nte + 1)
+res = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", "brute-force", plan=plan, distributed=True)
+if rank == 0:
+    ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", "brute-force", plan=plan)
+    for k in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):
+        assert np.array_equal(res[k], ref[k]), k
+    print("SHARDED_DRIVER_OK")
+else:
+    assert res is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_share_the_gpu_with_the_hip_fit(tmp_path):
+    # the N>1 path with the real compute: 2 ranks (started by torch.distributed.run before any GPU call), each fits its
+    # interleaved blocks with the HIP kernels on cuda:0, ONE gather; the gathered arrays equal the single-process result bit for bit
+    script = tmp_path / "w.py"
+    script.write_text(_SHARED_GPU_WORKER % {"root": ROOT, "pkg": PKG})
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "SHARED_GPU_OK 2" in p.stdout and "SHARDED_DRIVER_OK" in p.stdout

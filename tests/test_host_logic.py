@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import GOLDEN, ROOT, relmax
@@ -26,7 +27,7 @@ def test_library_builds_and_exports_header_symbols():
     for name in declared:
         assert hasattr(L, name), "libmet2_hip.so does not export %s" % name
     assert set(lib.SYMBOLS) == declared
-    assert L.met2_abi_version() == 1
+    assert L.met2_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -217,6 +218,31 @@ def test_shard_ranges():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
 
 
+def test_interleaved_shards_partition_the_voxel_list():
+    # block b of 4 096 voxels -> rank b mod world; every voxel exactly once, counts known up front
+    d = importlib.import_module(PKG + ".dist")
+    for n in (0, 1, 4095, 4096, 4097, 100000, 1048576, 5120000):
+        for w in (1, 2, 3, 8):
+            parts = [d.shard_indices(n, k, w) for k in range(w)]
+            assert [int(p.numel()) for p in parts] == [d.shard_count(n, k, w) for k in range(w)]
+            allv = torch.cat(parts)
+            assert allv.numel() == n and (n == 0 or bool((torch.sort(allv)[0] == torch.arange(n)).all()))
+            for k, p in enumerate(parts):
+                assert bool((((p // d.BLOCK) % w) == k).all())
+            if n >= w * d.BLOCK:
+                assert max(p.numel() for p in parts) - min(p.numel() for p in parts) <= d.BLOCK
+    small = [d.shard_indices(37, k, 3, block=4) for k in range(3)]
+    assert small[0].tolist() == [0, 1, 2, 3, 12, 13, 14, 15, 24, 25, 26, 27, 36]
+
+
+def test_sharding_without_a_process_group_is_an_error(monkeypatch):
+    d = importlib.import_module(PKG + ".dist")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(RuntimeError):
+        d.fit_sharded(lambda idx: {"reg": torch.zeros(idx.numel())}, 10, gather=("reg",), device=torch.device("cpu"))
+
+
 _GLOO_WORKER = r"""
 import os, sys, importlib
 sys.path.insert(0, %(root)r)
@@ -232,25 +258,34 @@ L = oracle.penalty(nt2, "L2")
 x = np.zeros((nvox, nt2)); x[:, 12] = rng.uniform(0.1, 0.3, nvox); x[:, 28] = rng.uniform(0.5, 1.0, nvox)
 data = (x @ D[0].T) * 1000.0 * (1 + 0.01 * rng.standard_normal((nvox, nte)))
 data = torch.as_tensor(np.abs(data))
-def fit_fn(blk, fa, mk):      # stand-in compute for the CPU rehearsal of the N>1 path (the checker, not the product)
+calls = {"n": 0}
+orig_gather = dist.gather
+def counting_gather(*a, **k):
+    calls["n"] += 1
+    return orig_gather(*a, **k)
+dist.gather = counting_gather
+def fit_fn(idx):      # stand-in compute for the CPU rehearsal of the N>1 path (the checker, not the product)
+    blk = data[idx]
     fs, sg, rg, st = oracle.fit_batch("X2", D, L, blk.numpy(), np.zeros(blk.shape[0]), np.ones(blk.shape[0]))
     maps = oracle.metrics(fs, T2s, np.ones(blk.shape[0]))
-    return {"maps": torch.as_tensor(np.stack([maps[k] for k in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC")])), "reg": torch.as_tensor(rg)}
-out, res = d.fit_sharded(fit_fn, data)
+    return {"maps": torch.as_tensor(np.stack([maps[k] for k in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC")])), "reg": torch.as_tensor(rg),
+            "fsol": torch.as_tensor(fs)}
+out, res = d.fit_sharded(fit_fn, nvox, gather=("maps", "reg", "fsol"), block=4, device=torch.device("cpu"))
+assert calls["n"] == 1, "the path has ONE collective, saw %%d" %% calls["n"]
 if rank == 0:
-    full = fit_fn(data, None, None)
+    full = fit_fn(torch.arange(nvox))
     assert res["maps"].shape == (6, nvox) and torch.equal(res["maps"], full["maps"]), "maps mismatch"
-    assert torch.equal(res["reg"], full["reg"])
+    assert torch.equal(res["reg"], full["reg"]) and torch.equal(res["fsol"], full["fsol"])
     print("GLOO_OK", world)
 else:
-    assert res["maps"] is None
+    assert res is None
 dist.barrier(); dist.destroy_process_group()
 """
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_fit_and_gather_gloo(tmp_path, world, oracle):
-    # the N>1 path (voxel blocks per rank + the single gather of the maps) rehearsed on CPU over gloo
+    # the N>1 path (interleaved voxel blocks per rank + the single packed gather) rehearsed on CPU over gloo
     script = tmp_path / "w.py"
     script.write_text(_GLOO_WORKER % {"root": ROOT, "pkg": PKG})
     port = 29600 + world + (os.getpid() % 200)
