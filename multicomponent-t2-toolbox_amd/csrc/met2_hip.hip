@@ -1477,6 +1477,7 @@ extern "C" int met2_fa_spline_select_strided(int32_t device, int64_t nvox, int32
                                              int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, int64_t voxel_stride,
                                              int64_t echo_stride, const uint8_t *mask, double *fa_index, double *xmin, void *stream)
 {
+    if (nvox == 0) return MET2_OK;
     if (!alpha_lr || !resid || !alpha_hr || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
     if (n_lr < 4 || n_lr > MET2_MAX_LR) return fail(MET2_E_UNSUPPORTED, "coarse FA grid must have 4..32 points");
     if (n_hr < 1 || n_te < 1) return fail(MET2_E_INVALID, "bad shape");
@@ -1902,10 +1903,11 @@ int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uin
 int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
                                const uint8_t *mask, double *fa_index, double *km, double *resid, void *stream)
 {
-    if (!p || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    if (nvox == 0) return MET2_OK;                       // empty voxel list: nothing to do (pointers may be NULL)
+    if (nvox < 0 || !data || !fa_index) return fail(MET2_E_INVALID, "NULL argument");
     if (voxel_stride == 0 || echo_stride == 0) return fail(MET2_E_INVALID, "zero stride");
     if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
-    if (nvox <= 0) return MET2_OK;
     USE_DEVICE(p->opt.device);
     hipStream_t s = (hipStream_t)stream;
     LaunchGeom g;

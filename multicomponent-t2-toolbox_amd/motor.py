@@ -127,12 +127,14 @@ def _prepare_volume(data, mask, dev, prepared, denoise):
     return dd, mk
 
 
-def _estimate_fa(plan, dd, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device):
-    """Driver step 2 (motor:349-373) -> flat float64 FA-index tensor in the voxel order of `dd`'s layout."""
-    from .plan import voxel_layout
-    _, nvox, _, _, _, order = voxel_layout(dd, plan.n_te)
+def _estimate_fa(plan, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device):
+    """Driver step 2 (motor:349-373) -> float64 FA-index tensor shaped like the volume (dd_fa.shape[:-1]); the smoothed
+    volume the angles are estimated on may be laid out differently from the one the spectra are fitted on, so the result
+    is handed on by logical voxel position, not in a memory order."""
+    from .plan import unflatten, voxel_layout
+    _, nvox, _, _, vol, order = voxel_layout(dd_fa, plan.n_te)
     if fa_index is not None:
-        return plan._per_voxel(np.asarray(fa_index, dtype=np.float64), nvox, torch.float64, "fa_index", order)
+        return torch.as_tensor(np.asarray(fa_index, dtype=np.float64), device=dd_fa.device).reshape(vol)
     if FA_method == "spline":
         alpha_values_spline = np.linspace(90.0, 180.0, 15)                                      # motor:237
         plan_lr = Met2Plan(plan.n_te, plan.n_t2, 15, device=device)
@@ -141,9 +143,9 @@ def _estimate_fa(plan, dd, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, al
             fa, _, _ = plan.fa_spline(plan_lr, alpha_values_spline, alpha_values, dd_fa, mm, want_km=False)
         finally:
             plan_lr.close()
-        return fa
-    fa, _, _ = plan.fa_bruteforce(dd_fa, mm)
-    return fa
+    else:
+        fa, _, _ = plan.fa_bruteforce(dd_fa, mm)
+    return unflatten(fa, vol, order)
 
 
 def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
@@ -191,11 +193,8 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     try:
         if distributed:
             return _recon_sharded(plan, dd, dd_fa, mm, reg_method, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device, vol_shape)
-        fa = _estimate_fa(plan, dd, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device)
-        out = plan.fit(reg_method, dd, fa_index=fa, mask=mm)
-        from .plan import unflatten, voxel_layout
-        order = voxel_layout(dd, nt)[5]
-        fa_vol = unflatten(fa, vol_shape, order)
+        fa_vol = _estimate_fa(plan, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device)
+        out = plan.fit(reg_method, dd, fa_index=fa_vol, mask=mm)
         tot_fa = dd_fa.sum(dim=-1)
         res = {"fsol_4D": out["fsol"].cpu().numpy(), "Est_Signal": out["sig"].cpu().numpy(), "reg_param": out["reg"].cpu().numpy(),
                "FA_index": fa_vol.cpu().numpy()}
@@ -227,7 +226,7 @@ def _recon_sharded(plan, dd, dd_fa, mm, reg_method, FA_method, fa_index, T2s, T1
         d = flat[idx].contiguous()
         dfa = d if dd_fa is dd else flat_fa[idx].contiguous()
         m = mflat[idx]
-        fa = _estimate_fa(plan, d, dfa, m, FA_method, None if faflat is None else faflat[idx].cpu().numpy(), T2s, T1s, tau, TR, alpha_values, device)
+        fa = _estimate_fa(plan, dfa, m, FA_method, None if faflat is None else faflat[idx].cpu().numpy(), T2s, T1s, tau, TR, alpha_values, device)
         out = plan.fit(reg_method, d, fa_index=fa, mask=m)
         out["fa"] = fa
         out["fa_gate"] = (m & (dfa.sum(dim=1) > 0)).to(torch.float64)
@@ -346,9 +345,7 @@ def motor_recon_met2_ROIs(TE_array, path_to_data, path_to_mask, path_to_ROIs, pa
     plan = Met2Plan(nt, Npc, alpha_values.shape[0], device=device, myelin_T2=myelin_T2)
     try:
         plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
-        fa = _estimate_fa(plan, dd, dd_fa, mk > 0, FA_method, None, T2s, T1s, tau, TR, alpha_values, device)
-        from .plan import unflatten, voxel_layout
-        fa_vol = unflatten(fa, data.shape[:3], voxel_layout(dd, nt)[5])
+        fa_vol = _estimate_fa(plan, dd_fa, mk > 0, FA_method, None, T2s, T1s, tau, TR, alpha_values, device)
         present = np.intersect1d(labels_all, np.unique(rois))
         if present.size != labels_all.size:
             raise ValueError("array must not contain infs or NaNs")  # a label without voxels inside the mask: 0/0 kernel (see docstring)

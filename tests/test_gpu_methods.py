@@ -31,8 +31,9 @@ def _single_fa_plan(pkg, g, pen):
 
 @pytest.mark.parametrize("pen", ["I", "L1", "L2", "InvT2"])
 def test_bayesreg_golden(pkg, gS1, pen):
-    # BR (bayesian_interpolation.py:84-126) against the reference.  InvT2: flat evidence minimum
-    #  -> 85 % of voxels < 1e-5, all < 2e-4, MWF < 1e-5; elsewhere 1e-5 on all.
+    # BR (bayesian_interpolation.py:84-126) against the reference.  InvT2: flat evidence minimum: on the
+    # 4 096-voxel fixture 7 % of voxels exceed 1e-5 (reference vs oracle: 6.5 %), all < 1.1e-4 (tests/test_tail_parity.py);
+    # on these 32 voxels measured 0 over 1e-5, max 9.0e-6 -> at most 6 (3x the 7 % rate), all < 2e-4, MWF < 1e-5.
     import torch
     g = gS1
     plan = _single_fa_plan(pkg, g, pen)
@@ -42,8 +43,9 @@ def test_bayesreg_golden(pkg, gS1, pen):
     lam = out["lam"].cpu().numpy()
     if pen == "L2":     # det(L2) = 0 -> objective +inf everywhere -> Brent's upper end point
         assert np.all(lam == 1.9999959949686712)
+    print("MEASURED bayes_golden %s n_over=%d of %d max=%.2e" % (pen, int((e >= TOL).sum()), e.shape[0], e.max()))
     if pen == "InvT2":
-        assert np.quantile(e, 0.85) < TOL and e.max() < 2e-4, e
+        assert int((e >= TOL).sum()) <= 6 and e.max() < 2e-4, e
     else:
         assert e.max() < TOL, e
     T2s = g["T2s"]
@@ -92,12 +94,16 @@ def test_gcv_distribution(pkg, gS1, pen):
     M = g["data"] / g["data"][:, :1]
     T2s = g["T2s"]
     mwf = lambda x: x[T2s <= 40.0].sum() / (x.sum() + 1e-16)
-    dm = []
+    dm = []; do = []
     for v in range(g["data"].shape[0]):
         o2 = oracle.objective("GCV", g["D150"], M[v], g["L_" + pen], np.array([lam[v], g["gcv_lam_" + pen][v]]))
-        assert o2[0] <= o2[1] + 0.2, (v, o2)
+        do.append(o2[0] - o2[1])
+        assert o2[0] <= o2[1] + 0.12, (v, o2)          # one step of the rank staircase is ~0.09 (measured max 8.9e-2)
         dm.append(abs(mwf(f[v]) - mwf(g["gcv_f_" + pen][v])))
-    assert np.median(dm) < 2e-3 and np.max(dm) < 6e-2, dm
+    print("MEASURED gcv_dist %s dobj max=%.3e median=%.3e  dMWF median=%.2e max=%.2e" % (pen, max(do), np.median(do), np.median(dm), np.max(dm)))
+    # measured: median |dMWF| 9.2e-8 (I) / 2.1e-7 (L2), max 6.2e-3 / 3.9e-5, median objective difference <= 0; the 4 096-voxel
+    # distribution against the reference is in tests/test_tail_parity.py
+    assert np.median(dm) < 1e-6 and np.max(dm) < 2e-2 and np.median(do) <= 1e-6, (dm, do)
     assert not (out["status"].cpu().numpy() & 32).any()
 
 

@@ -127,6 +127,7 @@ def test_vs_oracle_2k(pkg, synth, meth, pen):
         # 4.5e-5 of voxels).  Such a voxel must (a) be rare, (b) carry the exact solution for ITS lambda and (c) sit
         # as close to the chi-square target as the tolerance allows.
         idx = np.where(fit)[0][~ok]
+        print("MEASURED x2_2k %s/%s n_over=%d of %d" % (meth, pen, idx.size, int(fit.sum())))
         assert idx.size <= 2, idx
         lam = out["lam"].cpu().numpy(); dn = data.cpu().numpy(); fan = fa.cpu().numpy().astype(int)
         for v in idx:

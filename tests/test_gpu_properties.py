@@ -135,7 +135,8 @@ def test_dependent_columns_take_the_fallback(pkg):
     got = out["fsol"].cpu().numpy(); gs = out["sig"].cpu().numpy()
     e = np.max(np.abs(got - fs), axis=1) / np.max(np.abs(fs), axis=1)
     es = np.max(np.abs(gs - sg), axis=1) / np.max(np.abs(sg), axis=1)
-    assert np.mean(e < 1e-5) > 0.998 and np.mean(es < 1e-5) > 0.998, (e.max(), es.max())
+    print("MEASURED depcols n_over fsol=%d sig=%d of 3000, max %.2e %.2e" % (int((e >= 1e-5).sum()), int((es >= 1e-5).sum()), e.max(), es.max()))
+    assert e.max() < 1e-8 and es.max() < 1e-10, (e.max(), es.max())       # measured 1.0e-10 / 7.1e-14 on all 3 000 voxels
     # identical columns carry identical coefficients at the regularised optimum
     assert np.allclose(got[:, 20], got[:, 21], rtol=1e-6, atol=1e-9 * got.max())
     # a lambda grid that steps from 1e-2 straight down to 0: the warm start carries both twins into lambda = 0, where
@@ -225,12 +226,15 @@ def test_odd_shapes_vs_oracle(pkg, nte, nt2):
         e = np.max(np.abs(got - fs), axis=1) / np.max(np.abs(fs), axis=1)
         es = np.max(np.abs(gs - sg), axis=1) / np.max(np.abs(sg), axis=1)
         # the fitted signal is unique even where a near-degenerate dictionary (tiny nTE) leaves the spectrum loose
-        assert np.mean(es < 1e-5) >= 0.99, (meth, nte, nt2, es.max())
-        assert np.mean(e < 1e-5) >= (0.97 if nte >= 16 else 0.8), (meth, nte, nt2, np.mean(e < 1e-5), e.max())
+        print("MEASURED odd %s %dx%d n_over fsol=%d sig=%d of %d max %.2e %.2e" % (meth, nte, nt2, int((e >= 1e-5).sum()), int((es >= 1e-5).sum()), nvox, e.max(), es.max()))
+        # measured over the eight shapes: fsol max 6.0e-8, signal max 1.3e-9, no voxel of 300 over 1e-5
+        assert es.max() < 1e-7, (meth, nte, nt2, es.max())
+        assert e.max() < 2e-6, (meth, nte, nt2, e.max())
         assert (out["status"].cpu().numpy() & 1).all()
     idx, km, sse, ff, rs = oracle.fa_bruteforce(D, d, ones, nthreads=8, want_resid=True)
     fa_g, km_g, resid = plan.fa_bruteforce(data, None, want_resid=True)
-    assert np.mean(fa_g.cpu().numpy() == idx) > 0.99
+    print("MEASURED odd fa %dx%d mismatches=%d" % (nte, nt2, int((fa_g.cpu().numpy() != idx).sum())))
+    assert np.array_equal(fa_g.cpu().numpy(), idx)
     assert np.allclose(resid.cpu().numpy(), rs, rtol=1e-6, atol=1e-9 * np.abs(rs).max())
 
 
@@ -252,7 +256,9 @@ def test_alternative_kernel_paths_agree(pkg, monkeypatch):
     monkeypatch.delenv("MET2_STAGE")
     # (the staged kernel sums the model signal in another order, so a Brent tie may fall the other way in a rare voxel)
     e = (alt["fsol"] - ref["fsol"]).abs().max(dim=1).values / ref["fsol"].abs().max(dim=1).values
-    assert (e < 1e-8).double().mean().item() > 0.998 and torch.equal(alt["status"], ref["status"])
+    print("MEASURED altpaths n_over_1e-8=%d of 5000" % int((e >= 1e-8).sum().item()))
+    # measured: 8 of 5 000 voxels differ by more than 1e-8 (Brent ties), none by more than 1e-5
+    assert int((e >= 1e-8).sum().item()) <= 24 and int((e >= 1e-5).sum().item()) <= 2 and torch.equal(alt["status"], ref["status"])
     monkeypatch.setenv("MET2_FA_STAGE", "1")
     fa_alt, km_alt, res_alt = plan.fa_bruteforce(data, None, want_resid=True)
     monkeypatch.delenv("MET2_FA_STAGE")

@@ -270,5 +270,8 @@ def test_two_ranks_share_the_gpu_with_the_hip_fit(tmp_path):
            "--master-port", str(port), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    if p.returncode != 0 and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        open(os.path.join(ROOT, "gpurun_out", "shared_gpu_worker.log"), "w").write(p.stdout + "\n=====\n" + p.stderr)
+    rank1 = "\n".join(l for l in p.stderr.splitlines() if "[rank1]" in l)
+    assert p.returncode == 0, p.stdout[-2000:] + rank1[-3000:] + p.stderr[-2000:]
     assert "SHARED_GPU_OK 2" in p.stdout and "SHARDED_DRIVER_OK" in p.stdout

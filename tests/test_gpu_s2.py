@@ -106,8 +106,9 @@ def test_gcv_s2(pkg, gS2, pen):
     mwf = lambda x: x[T2s <= 40.0].sum() / (x.sum() + 1e-16)
     for v in range(nv):
         o2 = oracle.objective("GCV", g["D150"], M[v], g["L_" + pen], np.array([lam[v], g["gcv_lam_" + pen][v]]))
-        assert o2[0] <= o2[1] + 0.2, (v, o2)
-        assert abs(mwf(f[v]) - mwf(g["gcv_f_" + pen][v])) < 6e-2
+        print("MEASURED gcv_s2 %s v=%d dobj=%.3e dMWF=%.2e" % (pen, v, o2[0] - o2[1], abs(mwf(f[v]) - mwf(g["gcv_f_" + pen][v]))))
+        assert o2[0] <= o2[1] + 0.12, (v, o2)          # measured max 1.1e-5; 0.12 allows one step of the rank staircase
+        assert abs(mwf(f[v]) - mwf(g["gcv_f_" + pen][v])) < 1e-3        # measured max 7.2e-5
 
 
 def test_fa_and_rows_s2(pkg, gS2, plan91):
@@ -145,7 +146,8 @@ def test_s2_vs_oracle_maps(pkg, gS2, plan91):
     D = np.ascontiguousarray(np.transpose(plan91.get_dictionary(), (2, 0, 1)))
     fs, sg, rg, st = oracle.fit_batch("X2", D, oracle.penalty(120, "L2"), data.cpu().numpy(), fa.cpu().numpy(), np.ones(nvox), nthreads=8)
     e = relmax_rows(out["fsol"].cpu().numpy(), fs)
-    assert np.quantile(e, 0.99) < TOL and e.max() < 1e-2, (e.max(), np.quantile(e, 0.99))
+    print("MEASURED s2_maps n_over=%d of %d max=%.2e p99=%.2e" % (int((e >= TOL).sum()), nvox, e.max(), np.quantile(e, 0.99)))
+    assert e.max() < 1e-6, (e.max(), np.quantile(e, 0.99))           # measured max 3.8e-8, none of 256 over 1e-5
     mo = oracle.metrics(fs, g["T2s"], np.ones(nvox))
     maps = out["maps"].cpu().numpy()
     ok = e < TOL
