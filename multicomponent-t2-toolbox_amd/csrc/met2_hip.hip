@@ -440,12 +440,20 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 // MET2_STAGE=1): D and B of the workgroup's flip angle are copied to LDS and the workgroup shares FA-homogeneous chunks.
 // Waves per workgroup the kernel is compiled for: 16 (128 VGPRs) where the method fits that budget without
 // spilling (NNLS, T2SPARC, X2, L-curve), 12 (168 VGPRs) for the two with a second large phase (GCV, BayesReg).
-__host__ __device__ constexpr int method_max_waves(int method) { return (method <= MET2_LCURVE) ? 16 : 12; }
+#ifndef MET2_GCV_WAVES
+#define MET2_GCV_WAVES 8
+#endif
+__host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
+{
+    const int base = method >= 10 ? method - 10 : method;
+    if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills
+    return (method <= MET2_LCURVE) ? 16 : 12;
+}
 
 // SECOND only gives the second pass of the capacity scheme its own kernel symbol (profilers then list the
 // dominant first pass and the small clean-up pass separately); the code is identical.
 template <int METHOD, int NB, bool STAGE, bool SECOND>
-__global__ __launch_bounds__(64 * method_max_waves(METHOD)) void fit_kernel(FitArgs A)
+__global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(FitArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -1280,7 +1288,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     g.np = n | 1;
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
     g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
-    if (method == MET2_GCV && (m + 1) * (g.kmax + 2) > g.wave_doubles) g.wave_doubles = (m + 1) * (g.kmax + 2);   // E^T (k x (m+1)) + norms + rotation row, k <= kmax
+    if (method == MET2_GCV && gcv_lds_doubles(m, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(m, n);      // M ((m+1)^2) + vectors + support list
     // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
     // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
     // only ~k rows of B, so the fit kernel prefers the LDS for more resident waves per CU (measured on X2/L2:
@@ -1293,7 +1301,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
     int w = (int)((budget - shared) / per_wave);
-    const int wmax = method_max_waves(method);
+    const int wmax = method_max_waves(method, g.nb);
     if (w > wmax) w = wmax;
     if (const char *e = getenv("MET2_WAVES")) { int ww = atoi(e); if (ww >= 1 && ww < w) w = ww; }
     g.waves = w; g.block = 64 * w;
@@ -1309,18 +1317,6 @@ static int fast_kmax(const met2_plan *p, int method)
 {
     if (method == MET2_BAYESREG || method >= 10) return 0;
     if (const char *e = getenv("MET2_KMAX")) { int kk = atoi(e); return (kk >= 8 && kk < p->n_t2) ? kk : 0; }
-    if (method == MET2_GCV) {
-        // GCV's wave region holds the factor or its E^T matrix ((m+1) x (k+2)): the largest capacity that keeps the 12 waves
-        // the kernel is compiled for, but not below 0.6 n (measured: nT2 = 60: 36..48 -> 290 k voxels/s against 270 k at full
-        // capacity; nT2 = 120: 56 / 64 / 72 / 78 / full -> 17.7 / 24.8 / 30.3 / 30.3 / 14.9 k voxels/s)
-        const int mm = p->n_te + 1;
-        auto need = [&](int k) { size_t a = (size_t)k * (k + 1) / 2, b = (size_t)mm * (k + 2); return sizeof(double) * (a > b ? a : b); };
-        int k12 = 8;
-        while (12 * need(k12 + 1) <= 160 * 1024 - 64) ++k12;
-        int k = (3 * p->n_t2 + 4) / 5;
-        if (k12 > k) k = k12;
-        return k < p->n_t2 ? k : 0;
-    }
     // the largest capacity that still lets 16 waves share the LDS, but not below 0.6 n
     // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M;
     //  nT2 = 120 with the per-wave queue, where the clean-up pass is cheap: kmax 56 / 64 / 72 / 80 / 96 ->
@@ -1353,18 +1349,36 @@ static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s, bool
     return g.stage ? launch_fit_nb<METHOD, 1, true, false>(A, g, s) : launch_fit_nb<METHOD, 1, false, false>(A, g, s);
 }
 
+// -DMET2_ONLY=<method number> builds the fit kernel of that method only (plus plain NNLS): a development switch that
+// cuts the compile time of an experiment from ~80 s to ~15 s; the shipped library is built without it
+#ifdef MET2_ONLY
+#define MET2_HAS(m) ((m) == MET2_ONLY || (m) == 0)
+#else
+#define MET2_HAS(m) 1
+#endif
+
 static int launch_method(int method, const FitArgs &A, const LaunchGeom &g, hipStream_t s, bool second = false)
 {
     switch (method) {
+#if MET2_HAS(2)
     case 10 + MET2_X2: return launch_fit<10 + MET2_X2>(A, g, s);
-    case 10 + MET2_GCV: return launch_fit<10 + MET2_GCV>(A, g, s);
-    case 10 + MET2_BAYESREG: return launch_fit<10 + MET2_BAYESREG>(A, g, s);
-    case MET2_NNLS: return launch_fit<MET2_NNLS>(A, g, s, second);
-    case MET2_T2SPARC: return launch_fit<MET2_T2SPARC>(A, g, s, second);
     case MET2_X2: return launch_fit<MET2_X2>(A, g, s, second);
-    case MET2_LCURVE: return launch_fit<MET2_LCURVE>(A, g, s, second);
-    case MET2_GCV: return launch_fit<MET2_GCV>(A, g, s);
+#endif
+#if MET2_HAS(4)
+    case 10 + MET2_GCV: return launch_fit<10 + MET2_GCV>(A, g, s);
+    case MET2_GCV: return launch_fit<MET2_GCV>(A, g, s);      // its clean-up pass runs the same kernel symbol
+#endif
+#if MET2_HAS(5)
+    case 10 + MET2_BAYESREG: return launch_fit<10 + MET2_BAYESREG>(A, g, s);
     case MET2_BAYESREG: return launch_fit<MET2_BAYESREG>(A, g, s);
+#endif
+    case MET2_NNLS: return launch_fit<MET2_NNLS>(A, g, s, second);
+#if MET2_HAS(1)
+    case MET2_T2SPARC: return launch_fit<MET2_T2SPARC>(A, g, s, second);
+#endif
+#if MET2_HAS(3)
+    case MET2_LCURVE: return launch_fit<MET2_LCURVE>(A, g, s, second);
+#endif
     default: return fail(MET2_E_UNSUPPORTED, "method not built");
     }
 }
@@ -1868,8 +1882,9 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     if (dbg) {
         HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit kernel done\n");
 #ifdef MET2_CYCSTATS
-        unsigned long long cy[8];
+        unsigned long long cy[16];
         HIPCHK(hipMemcpyFromSymbol(cy, HIP_SYMBOL(met2::g_cyc), sizeof(cy)));
+        fprintf(stderr, "[met2] gcv trace: gram(mfma)=%llu tridiag=%llu bisect=%llu weights=%llu\n", cy[8], cy[9], cy[10], cy[11]);
         fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | slots 5-7 (bayes: chol, upper_times, erf/log; gcv small path: cycles, evaluations, sweeps; append slot += sum k)=%llu %llu %llu\n",
                 cy[0], cy[1], cy[2], cy[3], cy[4], cy[5], cy[6], cy[7]);
 #endif

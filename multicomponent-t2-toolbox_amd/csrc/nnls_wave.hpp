@@ -35,12 +35,12 @@ __device__ int g_loopstats[8];
 #endif
 
 #ifdef MET2_CYCSTATS
-__device__ unsigned long long g_cyc[8];
+__device__ unsigned long long g_cyc[16];
 #define MET2_CYC_BEGIN(var) const unsigned long long var = __builtin_readcyclecounter()
 #define MET2_CYC_END(slot, var) st.cyc[slot] += __builtin_readcyclecounter() - var
 #define MET2_CYC_ADD(slot, v) st.cyc[slot] += (unsigned long long)(v)
-#define MET2_CYC_INIT(st) do { for (int q_ = 0; q_ < 8; ++q_) st.cyc[q_] = 0; } while (0)
-#define MET2_CYC_FLUSH(st) do { if (lane_id() == 0) for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_cyc[q_], st.cyc[q_]); } while (0)
+#define MET2_CYC_INIT(st) do { for (int q_ = 0; q_ < 16; ++q_) st.cyc[q_] = 0; } while (0)
+#define MET2_CYC_FLUSH(st) do { if (lane_id() == 0) for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_cyc[q_], st.cyc[q_]); } while (0)
 #else
 #define MET2_CYC_BEGIN(var)
 #define MET2_CYC_END(slot, var)
@@ -81,7 +81,7 @@ struct NnlsState {
     u64 P[NB];         // passive-set mask   (uniform)
     int itmax_hit;     // uniform flags: bit0 iteration cap reached, bit1 passive set hit the capacity kmax < n
 #ifdef MET2_CYCSTATS
-    unsigned long long cyc[8];
+    unsigned long long cyc[16];
 #endif
 };
 

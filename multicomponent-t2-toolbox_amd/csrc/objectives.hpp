@@ -1,6 +1,7 @@
 // objectives.hpp -- lambda-selection objectives that need more than the NNLS solve:
 //   BayesReg  bayesian_interpolation.py:107-126  full n x n Cholesky of beta (B + lambda K), erf, log
-//   GCV       algorithms.py:285-296              truncated pseudo-inverse of the support Gram matrix
+//   GCV       algorithms.py:285-296              truncated pseudo-inverse of the support Gram matrix: MFMA Gram contraction,
+//                                                Householder tridiagonalisation, bisection, eigenvector weights
 // Both reuse the wave's LDS region once the NNLS solution is in st.x (the factor is rebuilt by the
 // next warm start).
 #pragma once
@@ -180,125 +181,230 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
     return cost1 + cost2;
 }
 
-// One-sided Jacobi on the k columns of E ((m+1) x k), for supports of at most 32 bins: E V = U Sigma, so after
-// convergence column r holds sigma_r u_r -- its squared norm is an eigenvalue of G = E^T E and its last entry over
-// sigma_r is U[m][r]; no rotation has to be accumulated.  Round-robin ordering over the k columns (k - 1 rounds of
-// up to 16 disjoint pairs instead of the m rounds of the E^T variant); a pair owns four lanes, each keeps its slice
-// of both columns (<= MET2_GCV_ROWS rows) in registers between the inner product and the rotation.
-// Returns trace(Dr G^+ Dr^T) = sum_{kept r} (1 - U[m][r]^2).
-#define MET2_GCV_ROWS 13                                      // ceil((n_te + 1) / 4) for n_te <= 51
-// column stride = 4 mod 32 doubles: the four lanes of a pair read consecutive rows, the 16 pairs of a round land
-// on banks 4 apart
-__device__ __forceinline__ int gcv_small_stride(int mm) { return ((mm + 27) / 32) * 32 + 4; }
-template <int NB>
-__device__ __forceinline__ double gcv_trace_small(const WaveShared &S, const int (&sp)[NB], int k, double sc, int lane, int &nsweep_done)
+// ------------------------------------------------------------------------------------------
+// GCV (algorithms.py:285-296).  With E = [Dr; sqrt(c) 1^T] ((m+1) x k; Dr = D restricted to the support of the NNLS
+// solution, c = lambda * sum_{j in S} L_jj^2 -- the scalar-broadcast quirk of algorithms.py:289-293) one has
+// G = Dr^T Dr + c 11^T = E^T E, so for E = U S V^T the truncated pseudo-inverse of np.linalg.lstsq(G, Dr^T, rcond=None)
+// gives   trace(Dr G^+ Dr^T) = sum_{kept i} (1 - U[m][i]^2),   kept: sigma_i^2 > eps k sigma_max^2.
+// sigma_i^2 and U[m][i] are the eigenvalues of M = E E^T ((m+1) x (m+1), 33 x 33 or 49 x 49 whatever the support size) and the
+// m-th components of its eigenvectors.  Direct method, no sweeps:
+//   1. M = A A^T with A = E, its sqrt(c) row moved to the front -- the batched Gram contraction of the path, on the matrix
+//      cores: v_mfma_f64_16x16x4 tiles whose operands are gathered straight from the L2-resident D^T rows of the support
+//      (nothing of E is staged); the symmetric result lands in the wave's LDS region;
+//   2. Householder tridiagonalisation T = Q^T M Q, lane <-> row.  The reflectors never touch index 0, so e_0^T Q = e_0^T and
+//      U[m][i] is the FIRST component of the i-th eigenvector of T;
+//   3. every lane isolates one eigenvalue of T by bisection on Sturm counts (LAPACK dstebz's recurrence; the midpoints are
+//      taken on the IEEE bit patterns, i.e. geometrically, because the spectrum spans 16 decades and the cut sits at its foot);
+//   4. the squared first component of an eigenvector is 1 / r_0'(mu) for the continued fraction r_j(x) = x - d_j -
+//      e_j^2 / r_{j+1}(x) (chi_T / chi_T' restricted to e_0), one backward recurrence per lane.
+// Forming M squares the condition number, which puts the rounding noise of the smallest kept eigenvalues where the
+// reference's own SVD of the explicitly formed G has it (measured on 900 (voxel, lambda) pairs in numpy: the objective differs
+// from the reference's formula by median 5.4e-6 / p99 6e-4 with this method and by 5.4e-6 / 6e-4 with an exact SVD of E; the
+// numerical rank agreed in every one).
+// ------------------------------------------------------------------------------------------
+typedef double met2_d4 __attribute__((ext_vector_type(4)));
+
+// LDS doubles a wave needs for it: M (n rows of stride np, three zero padding columns for the 4-wide loops), two padded
+// Householder vectors and the support list
+__host__ __device__ inline int gcv_row_stride(int m) { return (m + 1 + 3) | 1; }
+__host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = m + 1; return n * gcv_row_stride(m) + 2 * (n + 3) + (kcap + 1) / 2 + 2; }
+
+// Sturm count: number of eigenvalues < x (<= x up to the measure-zero case of an exactly vanishing minor) of the symmetric
+// tridiagonal matrix given as (d_j, e_{j-1}^2) pairs, by the sign changes of the leading principal minors
+// p_j(x) = (d_j - x) p_{j-1} - e_{j-1}^2 p_{j-2} (the quotients p_j / p_{j-1} are the pivots of LAPACK dstebz's recurrence; products
+// instead of divisions keep the dependent chain at two operations per row).  Two registers alternate as p_{j-1} / p_{j-2}, a sign
+// change is one xor of the high words, and the pair is rescaled by a power of two every eight rows (per row the minors grow by at
+// most the Gershgorin bound and shrink by no more than ~1e-16 of it).
+// Three shifts per lane at once: the three chains are independent (they hide each other's fp64 latency) and share the
+// row broadcasts.
+__device__ __forceinline__ void sturm_count3(double dreg, double e2reg, int n, const double (&x)[3], int (&out)[3])
 {
-    nsweep_done = 0;
-    const int m = S.m, mm = m + 1, mmp = gcv_small_stride(mm);
-    double *Bm = S.R;                                       // column r at Bm + r * mmp, rows 0..m
-    double *cn2 = Bm + k * mmp;                             // [k] squared column norms
-    {
-        const unsigned ec = (unsigned)min(lane, m - 1);
-        for (int r = 0; r < k; r += 4) {
-            double v[4];
+    // lane j holds (d_j, e_{j-1}^2); a row's pair reaches the scalar registers through v_readlane (no memory round trip)
+    double pa[3] = {1.0, 1.0, 1.0}, pb[3] = {0.0, 0.0, 0.0};     // p_{j-1}, p_{j-2}; after a row the roles swap
+    unsigned cnt[3] = {0u, 0u, 0u};
+    auto row2 = [&](int j) {                                     // rows j (-> pb) and j + 1 (-> pa)
+        const double d0 = bcast(dreg, j), f0 = bcast(e2reg, j), d1 = bcast(dreg, j + 1), f1 = bcast(e2reg, j + 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = min(r + q, k - 1);
-                const double *Drow = S.Dt + bcastN_i<NB>(sp, rr) * S.dtstride;
-                v[q] = Drow[ec];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (r + q < k && lane < mm) Bm[(r + q) * mmp + lane] = (lane < m) ? v[q] : sc;
+        for (int c = 0; c < 3; ++c) {
+            pb[c] = fma(d0 - x[c], pa[c], -(f0 * pb[c]));
+            cnt[c] += ((unsigned)(__double2hiint(pb[c]) ^ __double2hiint(pa[c]))) >> 31;
+            pa[c] = fma(d1 - x[c], pb[c], -(f1 * pa[c]));
+            cnt[c] += ((unsigned)(__double2hiint(pa[c]) ^ __double2hiint(pb[c]))) >> 31;
         }
+    };
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        row2(j); row2(j + 2); row2(j + 4); row2(j + 6);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(pa[c]), fabs(pb[c])));
+            pa[c] = ldexp(pa[c], -ex); pb[c] = ldexp(pb[c], -ex);
+        }
+    }
+    for (; j + 2 <= n; j += 2) row2(j);
+    if (j < n) {
+        const double d0 = bcast(dreg, j), f0 = bcast(e2reg, j);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pb[c] = fma(d0 - x[c], pa[c], -(f0 * pb[c]));
+            cnt[c] += ((unsigned)(__double2hiint(pb[c]) ^ __double2hiint(pa[c]))) >> 31;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = (int)cnt[c];
+}
+
+template <int NB>
+__device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, double sc, const int *list, int lane, unsigned long long *cyc = nullptr)
+{
+#ifdef MET2_CYCSTATS
+    unsigned long long tc0 = __builtin_readcyclecounter();
+#define MET2_GCV_LAP(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (cyc) cyc[slot] += t_ - tc0; tc0 = t_; } while (0)
+#else
+#define MET2_GCV_LAP(slot)
+#endif
+    const int m = S.m, n = m + 1, np = gcv_row_stride(m);
+    double *M = S.R;                         // [n][np], row a of lane a; row/column 0 = the sqrt(c) row of E
+    double *vb = M + n * np;                 // [n + 3] Householder vector, zero padded
+    double *wb = vb + n + 3;                 // [n + 3]
+    // ---- 1. M = A A^T on the matrix cores
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        const int nt = (n + 15) >> 4;
+        for (int ti = 0; ti < nt; ++ti)
+            for (int tj = ti; tj < nt; ++tj) {
+                met2_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                const int ra = 16 * ti + li, rb = 16 * tj + li;
+                const int ea = min(max(ra - 1, 0), m - 1), eb = min(max(rb - 1, 0), m - 1);
+                for (int r0 = 0; r0 < k; r0 += 16) {            // four k-steps per batch: eight operand loads in flight
+                    double a[4], b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = r0 + 4 * q + lk;
+                        const double *col = S.Dt + (size_t)list[min(rr, k - 1)] * S.dtstride;     // column s_rr of D, contiguous in D^T
+                        const double va = (ra == 0) ? sc : col[ea];
+                        const double vbb = (rb == 0) ? sc : col[eb];
+                        a[q] = (rr < k && ra < n) ? va : 0.0;
+                        b[q] = (rr < k && rb < n) ? vbb : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (r0 + 4 * q < k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * ti + lk + 4 * v, c = 16 * tj + li;
+                    if (row < n && c < n) { M[row * np + c] = acc[v]; M[c * np + row] = acc[v]; }
+                }
+            }
+        if (lane < n) { M[lane * np + n] = 0.0; M[lane * np + n + 1] = 0.0; M[lane * np + n + 2] = 0.0; }
+        if (lane < 3) { vb[n + lane] = 0.0; wb[n + lane] = 0.0; }
     }
     __builtin_amdgcn_wave_barrier();
-    const int odd = k & 1;
-    const int N = k + odd, nreal = N / 2 - odd;             // with k odd the fixed player is a dummy, its pair is skipped
-    const int pi = lane >> 2, sub = lane & 3;
-    const bool mine = pi < nreal;
-    const int ti = pi + odd;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        {
-            double t2 = 0.0;
-            if (lane < k) for (int e = 0; e < mm; ++e) { const double v = Bm[lane * mmp + e]; t2 = fma(v, v, t2); }
-            if (lane < k) cn2[lane] = t2;
-            __builtin_amdgcn_wave_barrier();
+    MET2_GCV_LAP(8);
+    // ---- 2. Householder tridiagonalisation (dsytd2, lower), lane a <-> row a
+    double dj = 0.0, ej = 0.0;               // lane j: T[j][j], T[j+1][j]
+    double *Mrow = M + min(lane, n - 1) * np;
+    for (int j = 0; j + 2 < n; ++j) {
+        const bool below = lane > j && lane < n;
+        const double x = below ? Mrow[j] : 0.0;
+        if (lane == j) dj = Mrow[j];
+        const double x0 = bcast(x, j + 1);
+        const double xn2 = wave_sum((lane > j + 1) ? x * x : 0.0);
+        if (xn2 == 0.0) { if (lane == j) ej = x0; continue; }       // column already in tridiagonal form
+        const double s2 = fma(x0, x0, xn2);
+        const double nx = s2 * rsqrt_nr(s2);
+        const double alpha = (x0 >= 0.0) ? -nx : nx;
+        const double v0 = x0 - alpha;
+        const double tau = 2.0 * rcp_nr(fma(v0, v0, xn2));            // H = I - tau v v^T
+        const double v = (lane == j + 1) ? v0 : x;                    // zero outside (j, n)
+        // p = tau M v, w = p - (tau/2)(p.v) v, M -= v w^T + w v^T on the trailing block: lane a walks its own row, v and w of
+        // the other rows are uniform-address LDS reads (broadcasting them with v_readlane instead costs six VALU instructions per
+        // matrix element and was measured 1.5x slower)
+        if (lane < n) vb[lane] = v;
+        __builtin_amdgcn_wave_barrier();
+        double p = 0.0, p2 = 0.0;
+        for (int b = j + 1; b < n; b += 4) {                          // may run into the zero padding
+            const double m0 = Mrow[b], m1 = Mrow[b + 1], m2 = Mrow[b + 2], m3 = Mrow[b + 3];
+            const double u0 = vb[b], u1 = vb[b + 1], u2 = vb[b + 2], u3 = vb[b + 3];
+            p = fma(m0, u0, p); p2 = fma(m1, u1, p2); p = fma(m2, u2, p); p2 = fma(m3, u3, p2);
         }
-        const double big = wave_max(lane < k ? cn2[lane] : 0.0);
-        const double floor2 = 1e-6 * (2.220446049250313e-16 * (double)k * big);
-        const double noise2 = 16.0 * 4.930380657631324e-32 * big * (double)mm;
-        u64 rotated = 0ull;
-        for (int rd = 0; rd < N - 1; ++rd) {
-            int ca, cb;
-            if (ti == 0) { ca = rd; cb = N - 1; }
-            else {
-                ca = rd + ti; ca = (ca >= N - 1) ? ca - (N - 1) : ca;
-                cb = rd - ti; cb = (cb < 0) ? cb + (N - 1) : cb;
+        p = below ? tau * (p + p2) : 0.0;
+        const double K = 0.5 * tau * wave_sum(p * v);
+        const double w = fma(-K, v, p);
+        if (lane < n) wb[lane] = w;
+        __builtin_amdgcn_wave_barrier();
+        if (below) {
+            for (int b = j + 1; b < n; b += 4) {
+                const double m0 = Mrow[b], m1 = Mrow[b + 1], m2 = Mrow[b + 2], m3 = Mrow[b + 3];
+                const double u0 = vb[b], u1 = vb[b + 1], u2 = vb[b + 2], u3 = vb[b + 3];
+                const double q0 = wb[b], q1 = wb[b + 1], q2 = wb[b + 2], q3 = wb[b + 3];
+                Mrow[b] = fma(-w, u0, fma(-v, q0, m0));
+                Mrow[b + 1] = fma(-w, u1, fma(-v, q1, m1));
+                Mrow[b + 2] = fma(-w, u2, fma(-v, q2, m2));
+                Mrow[b + 3] = fma(-w, u3, fma(-v, q3, m3));
             }
-            if (ca > cb) { int t = ca; ca = cb; cb = t; }
-            if (!mine) { ca = 0; cb = 0; }
-            double *pa = Bm + ca * mmp + sub, *pb = Bm + cb * mmp + sub;
-            double xa[MET2_GCV_ROWS], xb[MET2_GCV_ROWS];
-            double gamma = 0.0;
-#pragma unroll
-            for (int q = 0; q < MET2_GCV_ROWS; ++q) {
-                const bool in = sub + 4 * q < mm;
-                xa[q] = in ? pa[4 * q] : 0.0; xb[q] = in ? pb[4 * q] : 0.0;
-                gamma = fma(xa[q], xb[q], gamma);
-            }
-            const double alpha = mine ? cn2[ca] : 0.0, beta = mine ? cn2[cb] : 0.0;
-            gamma += __shfl_xor(gamma, 1);
-            gamma += __shfl_xor(gamma, 2);
-            const double g2 = gamma * gamma;
-            const bool rot = mine && !(alpha < floor2 && beta < floor2) && (g2 > 1e-30 * alpha * beta) && (g2 > noise2 * fmax(alpha, beta));
-            rotated |= ballot(rot);
-            const double a = beta - alpha, g = 2.0 * gamma;
-            const double h2 = fma(a, a, g * g);
-            const double hyp = (h2 > 0.0) ? h2 * rsqrt_nr(h2) : 0.0;
-            const double den = (a >= 0.0) ? a + hyp : a - hyp;
-            const double t = (den != 0.0) ? g * rcp_nr(den) : 0.0;
-            const double cs = rsqrt_nr(fma(t, t, 1.0)), sn = cs * t;
-            if (rot) {
-#pragma unroll
-                for (int q = 0; q < MET2_GCV_ROWS; ++q)
-                    if (sub + 4 * q < mm) { pa[4 * q] = cs * xa[q] - sn * xb[q]; pb[4 * q] = sn * xa[q] + cs * xb[q]; }
-                if (sub == 0) { cn2[ca] = alpha - t * gamma; cn2[cb] = beta + t * gamma; }
-            }
-            __builtin_amdgcn_wave_barrier();
         }
-        MET2_STAT(6, sweep + 1);
-        nsweep_done = sweep + 1;
-        if (!rotated) break;
+        if (lane == j) ej = alpha;
+        __builtin_amdgcn_wave_barrier();
     }
-    double t2 = 0.0, last = 0.0;
-    if (lane < k) {
-        for (int e = 0; e < mm; ++e) { const double v = Bm[lane * mmp + e]; t2 = fma(v, v, t2); }
-        last = Bm[lane * mmp + m];
+    if (lane == n - 2) { dj = Mrow[n - 2]; ej = M[(n - 1) * np + n - 2]; }
+    if (lane == n - 1) { dj = Mrow[n - 1]; ej = 0.0; }
+    // (d_j, e_{j-1}^2) pairs; Gershgorin bound
+    const double eg = gather(ej, (lane + 63) & 63);                    // cross-lane reads need the full wave: select afterwards
+    const double eprev = (lane > 0 && lane < n) ? eg : 0.0;
+    const double e2prev = eprev * eprev;                               // lane j: (d_j, e_{j-1}^2)
+    const double bound = fmax(wave_max((lane < n) ? fabs(dj) + fabs(ej) + fabs(eprev) : 0.0), 1e-300);
+    __builtin_amdgcn_wave_barrier();
+    MET2_GCV_LAP(9);
+    // ---- 3. bisection on the bit patterns: lane i -> the (i+1)-th largest eigenvalue
+    // the Gershgorin bound is at most sqrt(n) mu_max, so bound * 1e-18 lies below any cut eps k mu_max
+    unsigned long long lo = (unsigned long long)__double_as_longlong(bound * 1e-18);
+    unsigned long long hi = (unsigned long long)__double_as_longlong(bound * 1.0000001);
+    const int want = n - lane;                // eigenvalue number (1-based, ascending) this lane is after
+    for (int step = 0; step < 14; ++step) {   // two bits per step: 60 octaves -> 3 steps for the exponent, 11 for 22 bits of relative position (2.4e-7)
+        const unsigned long long q = (hi - lo) >> 2;
+        const unsigned long long m1 = lo + q, m2 = lo + 2 * q, m3 = lo + 3 * q;
+        const double xs[3] = {__longlong_as_double((long long)m1), __longlong_as_double((long long)m2), __longlong_as_double((long long)m3)};
+        int c[3];
+        sturm_count3(dj, e2prev, n, xs, c);
+        const bool u1 = c[0] >= want, u2 = c[1] >= want, u3 = c[2] >= want;       // at least `want` eigenvalues below the shift
+        hi = u1 ? m1 : (u2 ? m2 : (u3 ? m3 : hi));
+        lo = u1 ? lo : (u2 ? m1 : (u3 ? m2 : m3));
     }
-    const double smax = wave_max(lane < k ? t2 : 0.0);                   // eigenvalues of G = sigma(E)^2
-    const double cut = 2.220446049250313e-16 * (double)k * smax;
-    const bool keep = (lane < k) && (t2 > cut);
-    return wave_sum(keep ? (1.0 - last * last / t2) : 0.0);
+    const double mu = __longlong_as_double((long long)hi);
+    MET2_GCV_LAP(10);
+    // ---- 4. squared first eigenvector components: 1 / r_0'(mu)
+    const double pivmin = 1e-290;
+    double rp = 1.0;
+    {
+        double r = mu - bcast(dj, n - 1);
+        r = (fabs(r) < pivmin) ? pivmin : r;
+        for (int jj = n - 2; jj >= 0; --jj) {
+            const double e2 = bcast(e2prev, jj + 1);         // e_jj^2
+            const double inv = rcp_nr(r);
+            rp = fma(e2 * rp * inv, inv, 1.0);
+            r = fma(-e2, inv, mu - bcast(dj, jj));
+            r = (jj > 0 && fabs(r) < pivmin) ? pivmin : r;
+        }
+    }
+    const double w0 = rcp_nr(rp);
+    const double mumax = bcast(mu, 0);
+    const double cut = 2.220446049250313e-16 * (double)k * mumax;
+    const bool keep = (lane < n) && (mu > cut);
+    MET2_GCV_LAP(11);
+    return wave_sum(keep ? (1.0 - w0) : 0.0);
 }
 
 // algorithms.py:285-296 given the NNLS solution st.x at lambda = x:
-//   log( (r^2/m) / ((m - trace(Dr G^+ Dr^T))/m)^2 ),  G = Dr^T Dr + c 11^T,  c = x * sum_{j in S} L_jj^2
-// (the scalar-broadcast quirk of algorithms.py:289-293), G^+ = SVD-truncated pseudo-inverse with
-// np.linalg.lstsq's cutoff eps*k*s_max.  With E = [Dr; sqrt(c) 1^T] ((m+1) x k) one has G = E^T E, so
-// the singular values of G are the squared singular values of E and, for E = U S V^T,
-//   trace(Dr G^+ Dr^T) = sum_{kept i} (1 - U[m][i]^2).
-// E^T (k x (m+1)) is small in its column count whatever the support size: one-sided Jacobi on its
-// m+1 columns in a round-robin ordering that rotates up to 16 (nTE=32) or 24 (nTE=48) disjoint pairs at once,
-// carrying only the last row of the accumulated rotations.  Column norms are cached in LDS and refreshed
-// every sweep; pairs whose columns both sit far below the cutoff are skipped.
+//   log( (r^2/m) / ((m - trace(Dr G^+ Dr^T))/m)^2 )
 template <int NB>
 __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double x, double b,
                                                 int lane, int &overflow)
 {
-    const int n = S.n, m = S.m, mm = m + 1;
+    const int n = S.n, m = S.m;
 #ifdef MET2_CYCSTATS
     NnlsState<NB> &stw = const_cast<NnlsState<NB> &>(st);
-    const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
     const double sse = sse_of<NB>(S, st, b, lane);
     const double rn2 = sse + x * seminorm2<NB>(bd, st.x, n, lane);   // squared residual norm of the augmented system
@@ -315,10 +421,10 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         l2 += inS[bb] ? ld * ld : 0.0;
     }
     if (k == 0) return NAN;
-    if (mm * k + 2 * mm > S.rcap) { overflow = 1; return INFINITY; }
+    if (gcv_lds_doubles(m, k) > S.rcap || !S.Dt) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
-    // support list through LDS: rank-th support bin -> sp of the owner of row `rank`
-    int *list = (int *)S.R;
+    // support list (ascending bins) behind the matrices in the wave's LDS region
+    int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 2 * (m + 1 + 3));
     int base = 0;
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
@@ -327,108 +433,17 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         base += __popcll(Sm[bb]);
     }
     __builtin_amdgcn_wave_barrier();
-    int sp[NB];
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) sp[bb] = (lane + 64 * bb < k) ? list[lane + 64 * bb] : 0;
-    __builtin_amdgcn_wave_barrier();
-    double *A = S.R;                                   // column-major k x (m+1): A[e*k + r] = E[e][s_r]
-    double *cn2 = A + mm * k;                          // [mm] squared column norms
-    double *wl = cn2 + mm;                             // [mm] last row of the accumulated rotations
-    const double sc = sqrt(c);
-    if (k <= 32 && S.Dt && mm <= 4 * MET2_GCV_ROWS && k * gcv_small_stride(mm) + k <= S.rcap) {
 #ifdef MET2_CYCSTATS
-        const unsigned long long cs0 = __builtin_readcyclecounter();
+    const unsigned long long cs0 = __builtin_readcyclecounter();
 #endif
-        int nsw;
-        const double tr = gcv_trace_small<NB>(S, sp, k, sc, lane, nsw);
 #ifdef MET2_CYCSTATS
-        stw.cyc[5] += __builtin_readcyclecounter() - cs0; stw.cyc[6] += 1; stw.cyc[7] += nsw; stw.cyc[4] += k;
+    const double tr = gcv_trace_direct<NB>(S, k, sqrt(c), list, lane, stw.cyc);
+#else
+    const double tr = gcv_trace_direct<NB>(S, k, sqrt(c), list, lane);
 #endif
-        const double num = (1.0 / m) * rn2;
-        const double den = (1.0 / m) * ((double)m - tr);
-        return log(num / (den * den));
-    }
-    for (int e = 0; e < mm; ++e) {
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-            const int r = lane + 64 * bb;
-            if (r < k) A[e * k + r] = (e < m) ? S.D[e * S.dstride + sp[bb]] : sc;
-        }
-    }
-    if (lane < mm) wl[lane] = (lane == m) ? 1.0 : 0.0;
-    __builtin_amdgcn_wave_barrier();
-    // Round-robin ("tournament") ordering: N = mm rounded up to even players, N-1 rounds of N/2 disjoint column
-    // pairs; with mm odd the fixed player is a dummy and its pair is skipped.  Every pair gets LP lanes: the
-    // lanes of a pair split the k rows, partial inner products meet through LP-wide xor shuffles, and the
-    // rotation parameters (the expensive sqrt/div chain) are computed once per round for all pairs at once.
-    const int odd = mm & 1;
-    const int N = mm + odd, nreal = N / 2 - odd;
-    const int LP = (nreal <= 16) ? 4 : (nreal <= 32 ? 2 : 1);
-    const int pi = lane / LP, sub = lane - pi * LP;
-    const bool mine = pi < nreal;
-    const int ti = pi + odd;                           // pair index inside the round (0 = the fixed player's pair)
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        // refresh the cached column norms (lane e walks its own column)
-        {
-            double t2 = 0.0;
-            for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; t2 = fma(v, v, t2); }
-            if (lane < mm) cn2[lane] = t2;
-            __builtin_amdgcn_wave_barrier();
-        }
-        const double big = wave_max(lane < mm ? cn2[lane] : 0.0);
-        const double floor2 = 1e-6 * (2.220446049250313e-16 * (double)k * big);   // far below lstsq's cutoff on sigma^2
-        const double noise2 = 16.0 * 4.930380657631324e-32 * big * (double)k;      // (4 eps)^2 * big * k
-        u64 rotated = 0ull;
-        for (int rd = 0; rd < N - 1; ++rd) {
-            int ca, cb;
-            if (ti == 0) { ca = rd; cb = N - 1; }
-            else {                                      // (rd +- ti) mod (N-1): both operands are below N-1
-                ca = rd + ti; ca = (ca >= N - 1) ? ca - (N - 1) : ca;
-                cb = rd - ti; cb = (cb < 0) ? cb + (N - 1) : cb;
-            }
-            if (ca > cb) { int t = ca; ca = cb; cb = t; }
-            const double alpha = mine ? cn2[ca] : 0.0, beta = mine ? cn2[cb] : 0.0;
-            double gamma = 0.0;
-            if (mine) for (int r = sub; r < k; r += LP) gamma = fma(A[ca * k + r], A[cb * k + r], gamma);
-            if (LP >= 2) gamma += __shfl_xor(gamma, 1);
-            if (LP >= 4) gamma += __shfl_xor(gamma, 2);
-            const double g2 = gamma * gamma;
-            // converged pair: orthogonal to working precision, or the inner product is at the level of the absolute
-            // rounding noise (eps * sqrt(big) per entry) that cancellation left in small columns
-            const bool rot = mine && !(alpha < floor2 && beta < floor2) && (g2 > 1e-30 * alpha * beta) && (g2 > noise2 * fmax(alpha, beta));
-            rotated |= ballot(rot);
-            // rotation parameters through v_rsq_f64 / v_rcp_f64 + Newton steps instead of IEEE sqrt and divisions
-            // (a Jacobi rotation only has to be orthogonal, which cs and sn = cs t are to rounding)
-            const double a = beta - alpha, g = 2.0 * gamma;
-            const double h2 = fma(a, a, g * g);
-            const double hyp = (h2 > 0.0) ? h2 * rsqrt_nr(h2) : 0.0;
-            const double den = (a >= 0.0) ? a + hyp : a - hyp;
-            const double t = (den != 0.0) ? g * rcp_nr(den) : 0.0;           // tan of the rotation angle, |t| <= 1
-            const double cs = rsqrt_nr(fma(t, t, 1.0)), sn = cs * t;
-            if (rot) {
-                for (int r = sub; r < k; r += LP) {
-                    const double ap = A[ca * k + r], aq = A[cb * k + r];
-                    A[ca * k + r] = cs * ap - sn * aq;
-                    A[cb * k + r] = sn * ap + cs * aq;
-                }
-                if (sub == 0) {
-                    const double wp = wl[ca], wq = wl[cb];
-                    wl[ca] = cs * wp - sn * wq; wl[cb] = sn * wp + cs * wq;
-                    cn2[ca] = alpha - t * gamma; cn2[cb] = beta + t * gamma;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        MET2_STAT(6, sweep + 1);
-        if (!rotated) break;
-    }
-    double t2 = 0.0;
-    for (int r = 0; r < k; ++r) { double v = (lane < mm) ? A[lane * k + r] : 0.0; t2 = fma(v, v, t2); }
-    const double smax = wave_max(lane < mm ? t2 : 0.0);                  // singular values of G = sigma(E)^2
-    const double cut = 2.220446049250313e-16 * (double)k * smax;
-    const bool keep = (lane < mm) && (t2 > cut);
-    const double wv = (lane < mm) ? wl[lane] : 0.0;
-    const double tr = wave_sum(keep ? (1.0 - wv * wv) : 0.0);
+#ifdef MET2_CYCSTATS
+    stw.cyc[5] += __builtin_readcyclecounter() - cs0; stw.cyc[6] += 1; stw.cyc[4] += k;
+#endif
     const double num = (1.0 / m) * rn2;
     const double den = (1.0 / m) * ((double)m - tr);
     return log(num / (den * den));
