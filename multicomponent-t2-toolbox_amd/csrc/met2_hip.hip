@@ -441,12 +441,13 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 // Waves per workgroup the kernel is compiled for: 16 (128 VGPRs) where the method fits that budget without
 // spilling (NNLS, T2SPARC, X2, L-curve), 12 (168 VGPRs) for the two with a second large phase (GCV, BayesReg).
 #ifndef MET2_GCV_WAVES
-#define MET2_GCV_WAVES 8
+#define MET2_GCV_WAVES 16      // measured, GCV/L2 at 32x60, 131 072 voxels: 8 waves (198 VGPRs, no spills) 585 k voxels/s, 12 -> 687 k, 16 -> 710 k
 #endif
 __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 {
     const int base = method >= 10 ? method - 10 : method;
-    if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills
+    if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
+                                                                      // one bin per lane: the latency-bound recurrences want every wave the LDS can hold (14)
     return (method <= MET2_LCURVE) ? 16 : 12;
 }
 

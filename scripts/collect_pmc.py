@@ -9,7 +9,8 @@ one counter group (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
 domain other than --kernel-trace):
     --kernel-trace --stats                          per-kernel durations
     --pmc FETCH_SIZE / --pmc WRITE_SIZE             HBM bytes (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B)
-    --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F64 ...   instruction mix
+    --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS ... / SQ_WAVE_CYCLES SQ_WAIT_ANY ... / SQ_INSTS_VALU_FMA_F64 ... /
+          SQ_LDS_BANK_CONFLICT ... / SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES ...        instruction mix, waits, LDS, matrix cores
 and writes gpurun_out/<tag>_<key>_{kernel_stats,pmc}.csv plus an entry of gpurun_out/pmc_counters.json
 (copy both into profiles/ to have bench.py quote them; the entry carries the digest of the kernel sources it was taken on).
 The numbers describe the LAST timed launch of the dominant kernel (the one with the largest total time).
@@ -88,7 +89,10 @@ def main():
     groups = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("sq1", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]),
               ("sq2", ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"]),
-              ("mfma", ["SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64"])]
+              ("sq3", ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32",
+                       "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"]),
+              ("lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS_LOAD", "SQ_INSTS_LDS_STORE", "SQ_WAIT_INST_LDS"]),
+              ("mfma", ["SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_COEXEC_CYCLES"])]
     allc = {}
     for name, ctrs in groups:
         try:
@@ -114,6 +118,9 @@ def main():
         ent["hbm_bytes_per_launch"] = 1024.0 * (2.0 * allc["FETCH_SIZE"] + allc["WRITE_SIZE"])
     for src, dst in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("SQ_INSTS_SALU", "salu_insts_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
                      ("SQ_INSTS_MFMA", "mfma_insts_per_launch"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles"), ("SQ_WAIT_ANY", "sq_wait_any"),
+                     ("SQ_INSTS_VALU_FMA_F64", "valu_fma_f64"), ("SQ_INSTS_VALU_MUL_F64", "valu_mul_f64"), ("SQ_INSTS_VALU_ADD_F64", "valu_add_f64"),
+                     ("SQ_INSTS_VALU_TRANS_F64", "valu_trans_f64"), ("SQ_INSTS_VALU_INT32", "valu_int32"), ("SQ_INSTS_VALU_INT64", "valu_int64"),
+                     ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles"), ("SQ_LDS_IDX_ACTIVE", "lds_active_cycles"),
                      ("SQ_WAVE_CYCLES", "sq_wave_cycles"), ("SQ_ACTIVE_INST_VALU", "sq_active_inst_valu"), ("SQ_WAIT_INST_ANY", "sq_wait_inst_any")):
         if src in allc:
             ent[dst] = allc[src]
