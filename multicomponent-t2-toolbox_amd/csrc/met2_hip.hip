@@ -443,11 +443,15 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 #ifndef MET2_GCV_WAVES
 #define MET2_GCV_WAVES 16      // measured, GCV/L2 at 32x60, 131 072 voxels: 8 waves (198 VGPRs, no spills) 585 k voxels/s, 12 -> 687 k, 16 -> 710 k
 #endif
+#ifndef MET2_BAYES_WAVES
+#define MET2_BAYES_WAVES 12
+#endif
 __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 {
     const int base = method >= 10 ? method - 10 : method;
     if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
                                                                       // one bin per lane: the latency-bound recurrences want every wave the LDS can hold (14)
+    if (base == MET2_BAYESREG) return (nb == 2) ? 4 : MET2_BAYES_WAVES;  // two bins per lane: the full 120 x 120 factor leaves room for 2 waves per CU
     return (method <= MET2_LCURVE) ? 16 : 12;
 }
 

@@ -21,7 +21,7 @@ __device__ __forceinline__ double wave_prod(double v)
 // lane + 64 b, row j costs j independent LDS reads + FMAs in batches of four, the rows of B and of the dense K for
 // the next pivot are in flight meanwhile.  Returns false when a pivot is not positive (scipy raises LinAlgError there).
 template <int NB>
-__device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
+__device__ __forceinline__ bool chol_full_rowwise(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
 {
     const int n = S.n;
     const double bl = beta * lam;
@@ -118,6 +118,138 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
     return true;
 }
 
+typedef double met2_d4 __attribute__((ext_vector_type(4)));
+
+// The same factor by a blocked right-looking Cholesky with the trailing update on the matrix cores (the default; the row-wise
+// routine above stays behind -DMET2_CHOL_ROWWISE for A/B runs).  A = beta B + beta lam K is first written into the wave's
+// LDS region (upper triangle, packed by columns like U).  Then, per block row of 16:
+//   (a) its rows are finished row by row, lane <-> column, with the inner products restricted to the rows of the block
+//       (<= 15 terms instead of up to n - 1: everything above the block has already been subtracted by the trailing updates);
+//   (b) every trailing 16 x 16 tile C(ti, tj), ti <= tj, takes C -= U(block, ti)^T U(block, tj) as four v_mfma_f64_16x16x4
+//       (operands one f64 per lane straight from the packed columns, accumulator = the tile, four f64 per lane).
+// n = 60: 10 tile updates = 40 MFMAs and <= 15-term row sums instead of 59-term ones; n = 120: 84 tile updates = 336 MFMAs.
+template <int NB>
+__device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
+{
+#ifdef MET2_CHOL_ROWWISE
+    return chol_full_rowwise<NB>(S, bd, beta, lam, lane, det_u);
+#else
+    const int n = S.n;
+    const double bl = beta * lam;
+    int cbl[NB], cbc[NB];
+    unsigned jc[NB];
+    double diag[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        cbl[b] = col_base(pl);
+        cbc[b] = col_base(min(pl, n - 1));
+        jc[b] = (unsigned)min(pl, n - 1);
+        diag[b] = 1.0;
+    }
+    // ---- A into LDS, four rows of B and K in flight
+    for (int j = 0; j < n; j += 4) {
+        double vb[4][NB], vk[4][NB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jj = min(j + q, n - 1);
+            const double *Brow = S.B + jj * S.bstride, *Krow = S.K + jj * n;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { vb[q][b] = Brow[jc[b]]; vk[q][b] = Krow[jc[b]]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int c = lane + 64 * b;
+                if (j + q < n && c >= j + q && c < n) S.R[cbl[b] + j + q] = fma(bl, vk[q][b], beta * vb[q][b]);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int li = lane & 15, lk = lane >> 4;
+    const int nt = (n + 15) >> 4;
+    for (int kb = 0; kb < nt; ++kb) {
+        const int r0 = 16 * kb, r1 = min(n, r0 + 16);
+        // (a) the block's rows
+        for (int r = r0; r < r1; ++r) {
+            double a[NB], a2[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int c = lane + 64 * b; a[b] = (c >= r && c < n) ? S.R[cbl[b] + r] : 0.0; a2[b] = 0.0; }
+            const double *cr = S.R + col_base(r);                     // column r: U[j][r], j < r
+            int j = r0;
+            for (; j + 2 <= r; j += 2) {
+                const double s0 = cr[j], s1 = cr[j + 1];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const double *cc = S.R + cbc[b] + j;
+                    a[b] = fma(-s0, cc[0], a[b]); a2[b] = fma(-s1, cc[1], a2[b]);
+                }
+            }
+            if (j < r) {
+                const double s0 = cr[j];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + j], a[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) a[b] += a2[b];
+            const double d = bcastN<NB>(a, r);
+            if (!(d > 0.0)) return false;                             // scipy raises LinAlgError here
+            const double rinv = rsqrt_nr(d);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int c = lane + 64 * b;
+                const double u = a[b] * rinv;                         // lane r: d * rinv = U[r][r]
+                if (c >= r && c < n) S.R[cbl[b] + r] = u;
+                if (c == r) diag[b] = u;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // (b) trailing tiles on the matrix cores
+        for (int ti = kb + 1; ti < nt; ++ti) {
+            const int ca = 16 * ti + li;                              // this lane's column inside tile column ti
+            const int cba = col_base(min(ca, n - 1));
+            double aop[4];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int kr = r0 + 4 * sidx + lk;
+                const double v = S.R[cba + min(kr, r1 - 1)];
+                aop[sidx] = (ca < n && kr < r1) ? -v : 0.0;
+            }
+            for (int tj = ti; tj < nt; ++tj) {
+                const int cc = 16 * tj + li;
+                const int cbb = col_base(min(cc, n - 1));
+                double bop[4];
+                met2_d4 acc;
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int kr = r0 + 4 * sidx + lk;
+                    const double v = S.R[cbb + min(kr, r1 - 1)];
+                    bop[sidx] = (cc < n && kr < r1) ? v : 0.0;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * ti + lk + 4 * v;
+                    acc[v] = (cc < n && row <= cc) ? S.R[cbb + row] : 0.0;
+                }
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sidx], bop[sidx], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * ti + lk + 4 * v;
+                    if (cc < n && row <= cc) S.R[cbb + row] = acc[v];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    double dp = 1.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) dp *= (lane + 64 * b < n) ? diag[b] : 1.0;
+    det_u = wave_prod(dp);
+    return true;
+#endif
+}
+
 // (U f)_i for the factor in S.R; the owner of row i gets row i . f
 template <int NB>
 __device__ __forceinline__ void upper_times(const WaveShared &S, const double (&f)[NB], int lane, double (&out)[NB])
@@ -202,7 +334,7 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // from the reference's formula by median 5.4e-6 / p99 6e-4 with this method and by 5.4e-6 / 6e-4 with an exact SVD of E; the
 // numerical rank agreed in every one).
 // ------------------------------------------------------------------------------------------
-typedef double met2_d4 __attribute__((ext_vector_type(4)));
+
 
 // LDS doubles a wave needs for it: M (n rows of stride np, three zero padding columns for the 4-wide loops), two padded
 // Householder vectors and the support list
