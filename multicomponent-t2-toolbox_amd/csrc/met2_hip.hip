@@ -441,7 +441,8 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 // Waves per workgroup the kernel is compiled for: 16 (128 VGPRs) where the method fits that budget without
 // spilling (NNLS, T2SPARC, X2, L-curve), 12 (168 VGPRs) for the two with a second large phase (GCV, BayesReg).
 #ifndef MET2_GCV_WAVES
-#define MET2_GCV_WAVES 16      // measured, GCV/L2 at 32x60, 131 072 voxels: 8 waves (198 VGPRs, no spills) 585 k voxels/s, 12 -> 687 k, 16 -> 710 k
+#define MET2_GCV_WAVES 12      // measured, GCV/L2 at 32x60, 131 072 voxels: 8 waves per CU (198 VGPRs, no spills) 585 k voxels/s; 12 (168 VGPRs) 709 k
+                               // with 1.4 KB of HBM traffic per voxel; 16 (128 VGPRs) 729 k but 135 KB per voxel of scratch spills
 #endif
 #ifndef MET2_BAYES_WAVES
 #define MET2_BAYES_WAVES 12
@@ -450,7 +451,7 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 {
     const int base = method >= 10 ? method - 10 : method;
     if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
-                                                                      // one bin per lane: the latency-bound recurrences want every wave the LDS can hold (14)
+                                                                      // one bin per lane: the latency-bound recurrences want waves, the spills of a 128-VGPR build go to HBM
     if (base == MET2_BAYESREG) return (nb == 2) ? 4 : MET2_BAYES_WAVES;  // two bins per lane: the full 120 x 120 factor leaves room for 2 waves per CU
     return (method <= MET2_LCURVE) ? 16 : 12;
 }
