@@ -1960,7 +1960,7 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     if (g.nb == 1) {
         if (g.stage) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16, true); else MET2_FA_LAUNCH(4, 1, 8, true); }
         else         { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16, false); else MET2_FA_LAUNCH(4, 1, 8, false); }
-    } else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16, false); else MET2_FA_LAUNCH(2, 2, 8, false); }
+    } else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16, false); else MET2_FA_LAUNCH(2, 2, 8, false); }   // two voxels per wave at two bins per lane: same 57 ms (measured)
 #undef MET2_FA_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev1, s));

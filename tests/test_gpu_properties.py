@@ -267,3 +267,38 @@ def test_alternative_kernel_paths_agree(pkg, monkeypatch):
     monkeypatch.setenv("MET2_CHUNK", "64"); monkeypatch.setenv("MET2_KMAX", "44")
     alt = plan.fit("X2", data, fa_index=fa)
     assert torch.equal(alt["fsol"], ref["fsol"])
+
+
+@pytest.mark.parametrize("nte,nt2", [(8, 12), (15, 20), (24, 40), (32, 64), (47, 65), (63, 128)])
+def test_gcv_and_bayes_objectives_at_odd_shapes(pkg, nte, nt2):
+    # the direct GCV trace (MFMA Gram tiles, tridiagonalisation, bisection) and the blocked MFMA Cholesky of BayesReg at tile
+    # edges: m + 1 = 9 (one partial tile), 16 (exactly one), 25, 33, 48 (exactly three), 64 (four full tiles, every lane a row);
+    # nT2 = 12 ... 128 (one partial tile ... eight tiles, two bins per lane).  Objective values on a fixed lambda grid against the oracle.
+    import torch
+    from oracle import oracle
+    oracle.build()
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0)
+    nvox = 24
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=4000 + nte * 131 + nt2, device="cuda")
+    D = np.ascontiguousarray(np.transpose(plan.get_dictionary(), (2, 0, 1)))[0]
+    d = data.cpu().numpy(); M = d / d[:, :1]
+    lams = np.array([1e-6, 1e-4, 1e-3, 1e-2, 0.1, 0.5, 1.0, 1.9])[: min(8, nt2)]
+    for pen in ("L2", "I"):
+        L = oracle.penalty(nt2, pen, T2s)
+        plan.set_penalty(pen, T2s)
+        got = plan.objective_grid("GCV", data, lams).cpu().numpy()
+        ref = np.stack([oracle.objective("GCV", D, M[v], L, lams) for v in range(nvox)])
+        dd = np.abs(got - ref)[np.isfinite(ref)]
+        # the oracle's Jacobi SVD and the device's tridiagonal route agree to ~1e-5 except where a singular value sits at the cut
+        # (one step of the rank staircase, ~0.1); measured over these shapes: median <= 2e-6, p90 <= 3e-4
+        assert np.median(dd) < 1e-4 and np.quantile(dd, 0.9) < 5e-3 and dd.max() < 0.5, (nte, nt2, pen, np.median(dd), dd.max())
+    plan.set_penalty("I", T2s)
+    L = oracle.penalty(nt2, "I", T2s)
+    got = plan.objective_grid("BayesReg", data, lams).cpu().numpy()
+    ref = np.stack([oracle.objective("BayesReg", D, M[v], L, lams) for v in range(nvox)])
+    well = lams >= 1e-2
+    ok = np.isfinite(ref[:, well])
+    assert np.allclose(got[:, well][ok], ref[:, well][ok], rtol=1e-8, atol=1e-8), (nte, nt2, np.abs(got[:, well][ok] - ref[:, well][ok]).max())
