@@ -53,6 +53,7 @@ struct WaveShared {
     const double *B;    // [n][bstride]
     const double *K;    // [n][n] dense L^T L in global memory (fit kernel only)
     const double *Dt;   // [n][dtstride] transposed D in global memory, or NULL (then columns of D are read)
+    const double *DtG;  // the same array, always set (the GCV Gram contraction gathers its operands from it in every kernel variant)
     const double *kband; // [5][128] diagonals of K in global memory: kband[d*128 + j] = K[j][j+d-2] (loaded where the stencil is applied)
     int dtstride;
     const double *D;    // [m][dstride]

@@ -413,7 +413,7 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rr = r0 + 4 * q + lk;
-                        const double *col = S.Dt + (size_t)list[min(rr, k - 1)] * S.dtstride;     // column s_rr of D, contiguous in D^T
+                        const double *col = S.DtG + (size_t)list[min(rr, k - 1)] * S.dtstride;    // column s_rr of D, contiguous in D^T
                         const double va = (ra == 0) ? sc : col[ea];
                         const double vbb = (rb == 0) ? sc : col[eb];
                         a[q] = (rr < k && ra < n) ? va : 0.0;
@@ -553,7 +553,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         l2 += inS[bb] ? ld * ld : 0.0;
     }
     if (k == 0) return NAN;
-    if (gcv_lds_doubles(m, k) > S.rcap || !S.Dt) { overflow = 1; return INFINITY; }
+    if (gcv_lds_doubles(m, k) > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
     // support list (ascending bins) behind the matrices in the wave's LDS region
     int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 2 * (m + 1 + 3));
