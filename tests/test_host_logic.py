@@ -295,3 +295,34 @@ def test_sharded_fit_and_gather_gloo(tmp_path, world, oracle):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "GLOO_OK %d" % world in p.stdout
+
+
+def test_ctypes_argtypes_match_the_header_prototypes():
+    # every prototype of include/met2_hip.h against the argtypes the Python binding declares: same argument count, pointers
+    # where the header has pointers, 64-bit integers where it has int64_t (a drift here is a silent stack/register mismatch)
+    import ctypes as C
+    lib = importlib.import_module(PKG + "._lib")
+    L = lib.lib()
+    header = open(os.path.join(ROOT, "include", "met2_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|void|const char \*)\s*(met2_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert len(protos) >= 28
+    checked = 0
+    for name, args in protos:
+        fn = getattr(L, name)
+        if fn.argtypes is None:
+            continue
+        params = [a.strip() for a in args.replace("\n", " ").split(",") if a.strip() and a.strip() != "void"]
+        assert len(params) == len(fn.argtypes), (name, params, fn.argtypes)
+        for p, t in zip(params, fn.argtypes):
+            is_ptr = "*" in p
+            if is_ptr:
+                assert t is C.c_void_p or hasattr(t, "contents") or t is C.c_char_p, (name, p, t)
+            elif p.startswith("int64_t"):
+                assert t is C.c_int64, (name, p, t)
+            elif p.startswith("int32_t"):
+                assert t is C.c_int32, (name, p, t)
+            elif p.startswith("double"):
+                assert t is C.c_double, (name, p, t)
+        checked += 1
+    assert checked >= 20
