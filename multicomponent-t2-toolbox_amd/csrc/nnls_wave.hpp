@@ -618,7 +618,9 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         for (int b = 0; b < NB; ++b) { vb[b] = Brow[jc[b]]; vk[b] = Krow[jc[b]]; }
     };
     // finish a row: a holds A[i][c] - sum_{j<i} R[j][i] R[j][c]; scale, store column entries, one elimination step for y
-    auto finish = [&](int i, double (&a)[NB], double gdiag, double (&r)[NB]) -> bool {
+    // (the independence test of the pivots is done for all rows at once after the sweep: a non-positive or NaN pivot only
+    //  poisons the rows below it, and the whole factor is discarded then)
+    auto finish = [&](int i, double (&a)[NB], double (&r)[NB]) {
         const double d = bcastN<NB>(a, i);
         const double rinv = rsqrt_nr(d);
         const double yi = bcastN<NB>(g, i) * rinv;
@@ -629,8 +631,19 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
             if (pl >= i && pl < k) S.R[cbl[b] + i] = r[b];
             g[b] = (pl > i) ? fma(-r[b], yi, g[b]) : g[b];
         }
-        return !(d > 1e-14 * gdiag);
     };
+    // diagonal of G = B + lam K at the passive bins, by position (for the test after the sweep)
+    double gdp[NB];
+    {
+        double gdb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double bd0 = S.B[jc[b] * S.bstride + jc[b]], kd0 = S.K[jc[b] * n + jc[b]];
+            gdb[b] = fma(lam, kd0, bd0);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gdp[b] = gatherN<NB>(gdb, st.ord[b]);
+    }
     fetch(0, gb0, gk0);
     fetch(1, gb1, gk1);
     int cbi = 0;                                                        // col_base(i)
@@ -649,7 +662,6 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
 #pragma unroll
             for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); a2[b] = 0.0; c2[b] = 0.0; }
         }
-        const double gd0 = bcastN<NB>(a, i), gd1 = bcastN<NB>(c, i + 1);
         const double *ci = S.R + cbi, *cj = ci + i + 1;                 // columns i and i + 1
         int j = 0;
 #pragma clang loop unroll(disable)
@@ -672,11 +684,11 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         double r[NB], r1[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) { a[b] += a2[b]; c[b] += c2[b]; }
-        bad = finish(i, a, gd0, r) || bad;
+        finish(i, a, r);
         const double sr = bcastN<NB>(r, i + 1);                         // R[i][i+1]
 #pragma unroll
         for (int b = 0; b < NB; ++b) c[b] = fma(-sr, r[b], c[b]);
-        bad = finish(i + 1, c, gd1, r1) || bad;
+        finish(i + 1, c, r1);
         __builtin_amdgcn_wave_barrier();
         cbi += 2 * i + 3;                                               // col_base(i + 2) - col_base(i)
     }
@@ -689,7 +701,6 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
 #pragma unroll
             for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); a2[b] = 0.0; }
         }
-        const double gd0 = bcastN<NB>(a, i);
         const double *ci = S.R + cbi;
         int j = 0;
 #pragma clang loop unroll(disable)
@@ -711,16 +722,24 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         double r[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) a[b] += a2[b];
-        bad = finish(i, a, gd0, r) || bad;
+        finish(i, a, r);
         __builtin_amdgcn_wave_barrier();
+    }
+    // lane p: R[p][p]; its square is the pivot the row was scaled with: all pivots against the independence threshold of
+    // try_append at once (NaN from a negative pivot fails the comparison too)
+    double dgl[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        dgl[b] = (pl < k) ? S.R[cbl[b] + pl] : 1.0;
+        bad = bad || (ballot((pl < k) && !(dgl[b] * dgl[b] > 1e-14 * gdp[b])) != 0ull);
     }
     if (bad) return false;
     // lane p: 1 / R[p][p] and y_p = g_p / R[p][p] (g_p is final once rows < p are eliminated)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        const double dg = (pl < k) ? S.R[cbl[b] + pl] : 1.0;
-        const double ri = rcp_nr(dg);
+        const double ri = rcp_nr(dgl[b]);
         st.rinv[b] = (pl < k) ? ri : st.rinv[b];
         st.y[b] = (pl < k) ? g[b] * ri : st.y[b];
     }
