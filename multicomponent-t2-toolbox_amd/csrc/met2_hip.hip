@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m;
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     double *sR = sR0 + (size_t)wave * A.wave_doubles;
     int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;

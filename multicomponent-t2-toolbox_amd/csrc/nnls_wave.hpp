@@ -60,6 +60,7 @@ struct WaveShared {
     double *R;          // this wave's LDS region
     int n, m, bstride, dstride, kmax;
     int rcap;           // doubles available at R
+    bool brows_global;  // B and D point to global memory (false: the LDS copies of the staged kernel variants)
 };
 
 // L as 5 diagonals per owned bin: lb[b][d] = L[j][j+d-2].  (K = L^T L is not held in registers: its rows come from the
@@ -176,23 +177,34 @@ __device__ __forceinline__ void band_mul(const double (&bnd)[NB][5], const doubl
         out[b] = bnd[b][2] * v[b] + bnd[b][0] * m2[b] + bnd[b][1] * m1[b] + bnd[b][3] * p1[b] + bnd[b][4] * p2[b];
 }
 
-// 1/sqrt(d) to fp64 accuracy from v_rsq_f64 and two Newton steps (d > 0, normal range)
-__device__ __forceinline__ double rsqrt_nr(double d)
+// Row loads from the L2-resident matrices (B, K, D, D^T): element [row][col] of a row-major array whose row index is
+// wave-uniform and whose column differs per lane.  As a raw buffer load the uniform part travels in scalar registers
+// (descriptor = array base, soffset = row offset) and the lane part is one 32-bit VGPR byte offset: no VALU address
+// arithmetic at all.  The plain `base[row * stride + col]` costs one 64-bit v_lshl_add_u64 per load -- 3 500 of the X2 kernel's
+// 78 k VALU instructions per voxel.  Out-of-range offsets return 0 (the descriptor spans 1 GiB from the array base).
+__device__ __forceinline__ double ld_row(const double *array_base, int row_off_elems, unsigned lane_off_bytes)
 {
-    double r = __builtin_amdgcn_rsq(d);
-    const double hd = 0.5 * d;
-    double e = fma(-hd * r, r, 0.5);
-    r = fma(r, e, r);
-    e = fma(-hd * r, r, 0.5);
-    return fma(r, e, r);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)array_base, 0, 0x40000000, 0x00020000);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off_bytes, (unsigned)row_off_elems * 8u, 0);
+    return __hiloint2double((int)v[1], (int)v[0]);
 }
 
-// 1/d to fp64 accuracy from v_rcp_f64 and two Newton steps (d != 0, normal range)
+// 1/sqrt(d) to fp64 accuracy from v_rsq_f64 (relative error 5.2e-8, measured: scripts/probes/rsq_precision.hip) and ONE
+// third-order correction: with e = 1/2 - (d/2) r^2 = -delta - delta^2/2 the product r (1 + e + 3/2 e^2) = (1 + delta^3) / sqrt(d),
+// i.e. 1.4e-22 before rounding -- one instruction less than two Newton steps (d > 0, normal range)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    const double r = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(0.5 * d) * r, r, 0.5);
+    return fma(r, e * fma(1.5, e, 1.0), r);
+}
+
+// 1/d to fp64 accuracy from v_rcp_f64 (relative error 4.6e-8) and one third-order correction: r (1 + e + e^2), e = 1 - d r
 __device__ __forceinline__ double rcp_nr(double d)
 {
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(r, fma(-d, r, 1.0), r);
-    return fma(r, fma(-d, r, 1.0), r);
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 
 // Lawson-Hanson plane rotation (g1): c = a / sig, s = b / sig, sig = sqrt(a^2 + b^2) >= 0 (g1's two branches
@@ -334,8 +346,10 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = lane + 64 * b;
-        gb[b] = (j < S.n) ? S.B[t * S.bstride + j] : 0.0;
-        if (lam != 0.0) gb[b] = fma(lam, (j < S.n) ? S.K[t * S.n + j] : 0.0, gb[b]);       // G[j][t] (K is symmetric: row t)
+        const unsigned jo = 8u * (unsigned)min(j, S.n - 1);
+        const double bv = S.brows_global ? ld_row(S.B, t * S.bstride, jo) : S.B[t * S.bstride + min(j, S.n - 1)];
+        gb[b] = (j < S.n) ? bv : 0.0;
+        if (lam != 0.0) gb[b] = fma(lam, (j < S.n) ? ld_row(S.K, t * S.n, jo) : 0.0, gb[b]);       // G[j][t] (K is symmetric: row t)
     }
     const double gtt = bcastN<NB>(gb, t);
     double g[NB], rv[NB];
@@ -430,9 +444,9 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pp = min(p + q, k - 1);
-            const double *Brow = S.B + bcastN_i<NB>(st.ord, pp) * S.bstride;
+            const int trow = bcastN_i<NB>(st.ord, pp) * S.bstride;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) v[q][b] = Brow[jc[b]];
+            for (int b = 0; b < NB; ++b) v[q][b] = S.brows_global ? ld_row(S.B, trow, 8u * jc[b]) : S.B[trow + jc[b]];
             xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
         }
 #pragma unroll
@@ -613,9 +627,12 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
     // rows of B and K for pivots p and p + 1 (clamped to the last pivot)
     auto fetch = [&](int p, double (&vb)[NB], double (&vk)[NB]) {
         const int t = bcastN_i<NB>(st.ord, min(p, k - 1));
-        const double *Brow = S.B + t * S.bstride, *Krow = S.K + t * n;
+        const double *Brow = S.B + t * S.bstride;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { vb[b] = Brow[jc[b]]; vk[b] = Krow[jc[b]]; }
+        for (int b = 0; b < NB; ++b) {
+            vb[b] = S.brows_global ? ld_row(S.B, t * S.bstride, 8u * jc[b]) : Brow[jc[b]];
+            vk[b] = ld_row(S.K, t * n, 8u * jc[b]);
+        }
     };
     // finish a row: a holds A[i][c] - sum_{j<i} R[j][i] R[j][c]; scale, store column entries, one elimination step for y
     // (the independence test of the pivots is done for all rows at once after the sweep: a non-positive or NaN pivot only
@@ -652,7 +669,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
     // two rows per step: rows i and i + 1 share the reads of the rows above them, and row i + 1 takes row i's
     // contribution from registers, so the pair costs one LDS round trip instead of two
     for (; i + 1 < k; i += 2) {
-        double a[NB], a2[NB], c[NB], c2[NB];
+        double a[NB], c[NB];
         {
             double t0[NB], t1[NB];
 #pragma unroll
@@ -660,7 +677,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
             fetch(i + 2, gb0, gk0);
             fetch(i + 3, gb1, gk1);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); a2[b] = 0.0; c2[b] = 0.0; }
+            for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); }
         }
         const double *ci = S.R + cbi, *cj = ci + i + 1;                 // columns i and i + 1
         int j = 0;
@@ -672,8 +689,8 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
             for (int b = 0; b < NB; ++b) {
                 const double *cc = S.R + cbc[b] + j;
                 const double q0 = cc[0], q1 = cc[1];
-                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
-                c[b] = fma(-u0, q0, c[b]); c2[b] = fma(-u1, q1, c2[b]);
+                a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);      // the two rows are the two independent chains
+                a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
             }
         }
         for (; j < i; ++j) {
@@ -682,8 +699,6 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
             for (int b = 0; b < NB; ++b) { const double q0 = S.R[cbc[b] + j]; a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]); }
         }
         double r[NB], r1[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { a[b] += a2[b]; c[b] += c2[b]; }
         finish(i, a, r);
         const double sr = bcastN<NB>(r, i + 1);                         // R[i][i+1]
 #pragma unroll
@@ -799,8 +814,7 @@ __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsSt
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pp = min(p + q, k - 1);
-                const double *Drow = S.Dt + bcastN_i<NB>(st.ord, pp) * S.dtstride;
-                v[q] = Drow[ec];
+                v[q] = ld_row(S.Dt, bcastN_i<NB>(st.ord, pp) * S.dtstride, 8u * ec);
                 xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
             }
             acc = fma(v[0], xs[0], acc); acc2 = fma(v[1], xs[1], acc2);

@@ -153,9 +153,11 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int jj = min(j + q, n - 1);
-            const double *Brow = S.B + jj * S.bstride, *Krow = S.K + jj * n;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { vb[q][b] = Brow[jc[b]]; vk[q][b] = Krow[jc[b]]; }
+            for (int b = 0; b < NB; ++b) {
+                vb[q][b] = S.brows_global ? ld_row(S.B, jj * S.bstride, 8u * jc[b]) : S.B[jj * S.bstride + jc[b]];
+                vk[q][b] = ld_row(S.K, jj * n, 8u * jc[b]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
