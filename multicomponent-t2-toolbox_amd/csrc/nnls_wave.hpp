@@ -682,16 +682,30 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         const double *ci = S.R + cbi, *cj = ci + i + 1;                 // columns i and i + 1
         int j = 0;
 #pragma clang loop unroll(disable)
-        for (; j + 2 <= i; j += 2) {                                    // two rows above per step (one ds_read2 per column)
+        for (; j + 4 <= i; j += 4) {                                    // four rows above per step: the three LDS pointers are bumped once per eight FMAs
+            const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
+            const double u0 = cj[j], u1 = cj[j + 1], u2 = cj[j + 2], u3 = cj[j + 3];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double *cc = S.R + cbc[b] + j;
+                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);      // the two rows are the two independent chains
+                a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
+                a[b] = fma(-s2, q2, a[b]); c[b] = fma(-u2, q2, c[b]);
+                a[b] = fma(-s3, q3, a[b]); c[b] = fma(-u3, q3, c[b]);
+            }
+        }
+        if (j + 2 <= i) {                                               // two rows above (one ds_read2 per column)
             const double s0 = ci[j], s1 = ci[j + 1];
             const double u0 = cj[j], u1 = cj[j + 1];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const double *cc = S.R + cbc[b] + j;
                 const double q0 = cc[0], q1 = cc[1];
-                a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);      // the two rows are the two independent chains
+                a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);
                 a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
             }
+            j += 2;
         }
         for (; j < i; ++j) {
             const double s0 = ci[j], u0 = cj[j];
