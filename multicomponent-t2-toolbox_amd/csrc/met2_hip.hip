@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE;
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     double *sR = sR0 + (size_t)wave * A.wave_doubles;
     int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE; S.buffer_rows = false; S.have_bdiag = true; S.bdiag[0] = S.bdiag[1] = 0.0;
     if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
     else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
     Band<NB> bd;
@@ -767,6 +767,8 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
                 st[0].cyc[5] += cs1 - cs0; st[0].cyc[6] += __builtin_readcyclecounter() - cs1;
 #endif
             } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) { const int j = min(lane + 64 * bb, n - 1); S.bdiag[bb] = Bf[(size_t)j * n + j]; }
 #ifdef MET2_CYCSTATS
             const unsigned long long cv0 = __builtin_readcyclecounter();
 #endif

@@ -61,6 +61,10 @@ struct WaveShared {
     int n, m, bstride, dstride, kmax;
     int rcap;           // doubles available at R
     bool brows_global;  // B and D point to global memory (false: the LDS copies of the staged kernel variants)
+    bool have_bdiag;    // bdiag holds B[j][j] of the lane's bins (the FA walk sets it once per flip angle: its refactorisations are too
+    double bdiag[2];    // short -- k ~ 8 -- to hide the latency of loading the diagonal inside refactor())
+    bool buffer_rows;   // row loads of the global matrices as raw buffer loads (fit kernels); false: plain global loads (the FA walk, whose
+                        // 19 MB of dictionaries at 48 x 120 missed L2 1.7x more often through the buffer path: 57 -> 66 ms per 131 k voxels)
 };
 
 // L as 5 diagonals per owned bin: lb[b][d] = L[j][j+d-2].  (K = L^T L is not held in registers: its rows come from the
@@ -187,6 +191,11 @@ __device__ __forceinline__ double ld_row(const double *array_base, int row_off_e
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)array_base, 0, 0x40000000, 0x00020000);
     const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off_bytes, (unsigned)row_off_elems * 8u, 0);
     return __hiloint2double((int)v[1], (int)v[0]);
+}
+
+__device__ __forceinline__ double ld_row_sel(bool buffer, const double *array_base, int row_off_elems, unsigned lane_elem)
+{
+    return buffer ? ld_row(array_base, row_off_elems, 8u * lane_elem) : array_base[row_off_elems + (int)lane_elem];
 }
 
 // 1/sqrt(d) to fp64 accuracy from v_rsq_f64 (relative error 5.2e-8, measured: scripts/probes/rsq_precision.hip) and ONE
@@ -346,10 +355,10 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = lane + 64 * b;
-        const unsigned jo = 8u * (unsigned)min(j, S.n - 1);
-        const double bv = S.brows_global ? ld_row(S.B, t * S.bstride, jo) : S.B[t * S.bstride + min(j, S.n - 1)];
+        const unsigned je = (unsigned)min(j, S.n - 1);
+        const double bv = ld_row_sel(S.brows_global && S.buffer_rows, S.B, t * S.bstride, je);
         gb[b] = (j < S.n) ? bv : 0.0;
-        if (lam != 0.0) gb[b] = fma(lam, (j < S.n) ? ld_row(S.K, t * S.n, jo) : 0.0, gb[b]);       // G[j][t] (K is symmetric: row t)
+        if (lam != 0.0) gb[b] = fma(lam, (j < S.n) ? ld_row_sel(S.buffer_rows, S.K, t * S.n, je) : 0.0, gb[b]);       // G[j][t] (K is symmetric: row t)
     }
     const double gtt = bcastN<NB>(gb, t);
     double g[NB], rv[NB];
@@ -446,7 +455,7 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
             const int pp = min(p + q, k - 1);
             const int trow = bcastN_i<NB>(st.ord, pp) * S.bstride;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) v[q][b] = S.brows_global ? ld_row(S.B, trow, 8u * jc[b]) : S.B[trow + jc[b]];
+            for (int b = 0; b < NB; ++b) v[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, trow, jc[b]);
             xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
         }
 #pragma unroll
@@ -627,11 +636,10 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
     // rows of B and K for pivots p and p + 1 (clamped to the last pivot)
     auto fetch = [&](int p, double (&vb)[NB], double (&vk)[NB]) {
         const int t = bcastN_i<NB>(st.ord, min(p, k - 1));
-        const double *Brow = S.B + t * S.bstride;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            vb[b] = S.brows_global ? ld_row(S.B, t * S.bstride, 8u * jc[b]) : Brow[jc[b]];
-            vk[b] = ld_row(S.K, t * n, 8u * jc[b]);
+            vb[b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, t * S.bstride, jc[b]);
+            vk[b] = ld_row_sel(S.buffer_rows, S.K, t * n, jc[b]);
         }
     };
     // finish a row: a holds A[i][c] - sum_{j<i} R[j][i] R[j][c]; scale, store column entries, one elimination step for y
@@ -655,8 +663,8 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         double gdb[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const double bd0 = S.B[jc[b] * S.bstride + jc[b]], kd0 = S.K[jc[b] * n + jc[b]];
-            gdb[b] = fma(lam, kd0, bd0);
+            const double bd0 = S.have_bdiag ? S.bdiag[b] : S.B[jc[b] * S.bstride + jc[b]];
+            gdb[b] = (lam != 0.0) ? fma(lam, S.K[jc[b] * n + jc[b]], bd0) : bd0;
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) gdp[b] = gatherN<NB>(gdb, st.ord[b]);
@@ -828,7 +836,7 @@ __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsSt
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pp = min(p + q, k - 1);
-                v[q] = ld_row(S.Dt, bcastN_i<NB>(st.ord, pp) * S.dtstride, 8u * ec);
+                v[q] = ld_row_sel(S.buffer_rows, S.Dt, bcastN_i<NB>(st.ord, pp) * S.dtstride, ec);
                 xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
             }
             acc = fma(v[0], xs[0], acc); acc2 = fma(v[1], xs[1], acc2);

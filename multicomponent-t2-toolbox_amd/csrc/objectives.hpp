@@ -155,8 +155,8 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
             const int jj = min(j + q, n - 1);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                vb[q][b] = S.brows_global ? ld_row(S.B, jj * S.bstride, 8u * jc[b]) : S.B[jj * S.bstride + jc[b]];
-                vk[q][b] = ld_row(S.K, jj * n, 8u * jc[b]);
+                vb[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, jj * S.bstride, jc[b]);
+                vk[q][b] = ld_row_sel(S.buffer_rows, S.K, jj * n, jc[b]);
             }
         }
 #pragma unroll
