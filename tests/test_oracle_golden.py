@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/met2_oracle.c) to golden vectors produced by running the
 reference itself (tests/golden/make_goldens.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,3 +231,48 @@ def test_brent_analytic(oracle):
         assert len(txs) == len(xs)
         assert np.allclose(txs, xs, rtol=1e-12, atol=1e-15)
         assert abs(xo - xref) <= 1e-14 * max(1.0, abs(xref))
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    # the CPU restatement built with -fsanitize=address,undefined (oracle/Makefile: libmet2_oracle_asan.so) runs
+    # every method on a handful of voxels at both shapes without a report (GPU sanitizers are not available on the pool)
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["make", "-C", odir, "libmet2_oracle_asan.so"], stdout=subprocess.DEVNULL)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found")
+    code = r"""
+import ctypes as C, numpy as np, sys
+L = C.CDLL(%r)
+dp = C.POINTER(C.c_double)
+P = lambda a: a.ctypes.data_as(dp)
+rng = np.random.default_rng(3)
+for nte, nt2 in ((32, 60), (48, 120), (8, 12)):
+    T2s = np.logspace(1, np.log10(2000.0), nt2); T1s = 1000.0 * np.ones(nt2); al = np.array([120.0, 150.0, 180.0])
+    D = np.zeros((3, nte, nt2))
+    L.met2o_dictionary(nte, nt2, 3, P(T2s), P(T1s), C.c_double(10.0), P(al), C.c_double(3000.0), P(D))
+    nvox = 6
+    x = np.zeros((nvox, nt2)); x[:, nt2 // 5] = 0.2; x[:, nt2 // 2] = 0.8
+    data = np.abs((x @ D[1].T) * 1000.0 * (1 + 0.01 * rng.standard_normal((nvox, nte))))
+    data[4] = 0.0
+    fa = np.array([0.0, 1.0, 2.0, 1.0, 1.0, 2.0]); mask = np.array([1.0, 1.0, 1.0, 0.0, 1.0, 1.0])
+    lam = np.zeros(50); lam[1:] = np.logspace(-8, 1, 49)
+    for pen in range(4):
+        Lm = np.zeros((nt2, nt2)); L.met2o_penalty(nt2, pen, P(T2s), P(Lm))
+        for meth in range(6):
+            fs = np.zeros((nvox, nt2)); sg = np.zeros((nvox, nte)); rg = np.zeros(nvox); ll = np.zeros(nvox); st = np.zeros(nvox, dtype=np.int32)
+            rc = L.met2o_fit_batch_lam(meth, nte, nt2, 3, P(D), P(Lm), P(lam), 50, C.c_double(1.02), C.c_double(1.8), C.c_int64(nvox), P(data), P(fa), P(mask),
+                                       P(fs), P(sg), P(rg), P(ll), st.ctypes.data_as(C.POINTER(C.c_int32)), 1)
+            assert rc == 0 and np.isfinite(fs).all()
+    idx = np.zeros(nvox); km = np.zeros(nvox); sse = np.zeros(nvox); f = np.zeros((nvox, nt2)); rs = np.zeros((nvox, 3))
+    L.met2o_fa_bruteforce(nte, nt2, 3, P(D), C.c_int64(nvox), P(data), P(mask), P(idx), P(km), P(sse), P(f), P(rs), 1)
+    maps = np.zeros((6, nvox)); L.met2o_metrics(nt2, P(T2s), C.c_double(40.0), C.c_double(200.0), C.c_int64(nvox), P(fs), P(mask), P(maps))
+print("ASAN_OK")
+""" % os.path.join(odir, "libmet2_oracle_asan.so")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "ASAN_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-4000:]
