@@ -11,6 +11,9 @@ run --dims 64,64,32 --method GCV --penalty L2
 run --dims 64,64,64 --method NNLS --penalty I
 run --dims 64,64,64 --method T2SPARC --penalty InvT2
 run --dims 32,32,32 --method X2 --penalty L2 --nte 48 --nt2 120
+run --dims 32,32,32 --method BayesReg --penalty InvT2 --nte 48 --nt2 120
+run --dims 64,64,32 --method GCV --penalty L2 --nte 48 --nt2 120
+run --dims 64,64,64 --method X2 --penalty L2 --fa brute-force
 python3 - <<PY
 import json
 for l in open("$O"):
