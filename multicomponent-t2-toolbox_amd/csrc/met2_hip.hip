@@ -260,6 +260,8 @@ struct FitArgs {
     double *fsol, *sig, *reg, *lam, *maps;
     int32_t *status;
     int64_t nvox;
+    const double *seed_x;                 // [nfa][128] first-Brent-point seeds of the method (seed_kernel), or NULL
+    const int *seed_pos, *seed_ord, *seed_k;
 };
 
 // SciPy's bounded Brent (scipy.optimize.fminbound, called at algorithms.py:219,280 and
@@ -456,6 +458,74 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
     return (method <= MET2_LCURVE) ? 16 : 12;
 }
 
+// Seeds for the first Brent point.  The first abscissa of scipy's bounded Brent is a + 0.382 (b - a) for every voxel, and at
+// that (large) lambda the passive set is broad and nearly the same for all voxels of a flip angle, while the lambda = 0
+// solution a voxel would otherwise start from has ~8 bins: growing it to ~44 bin by bin (one forward substitution, one
+// triangular solve and one dual per bin) was ~10 % of the X2 kernel.  seed_kernel solves one canonical signal (a two-peak
+// spectrum pushed through the flip angle's dictionary) at that lambda per flip angle when the plan's dictionary or penalty
+// changes; every voxel's first evaluation starts from that passive set and iterate: one refactorisation and a few exchanges.
+// Any x >= 0 is a feasible start for Lawson-Hanson and the regularised problem is strictly convex, so the solution is the
+// cold-start one up to rounding, and because the seed depends on the plan only, a voxel's result stays independent of its
+// neighbours and of the order of the voxel list.  The lambda = 0 solves keep the cold path: x(0) need not be unique and NNLS,
+// the L-curve and BayesReg's degrees of freedom use x(0) itself.
+struct SeedArgs {
+    int n, m, nfa;
+    const double *Dfa, *Bfa, *Dtfa, *kband, *lband, *Kd;
+    double lam[2];          // slot 0: X2 and GCV (bounds 0 / 1e-8 .. 10), slot 1: BayesReg (1e-8 .. 2)
+    double *x;              // [2][nfa][128]  bin-indexed iterate
+    int *pos, *ord;         // [2][nfa][128]  bin -> position (-1 outside the set), position -> bin
+    int *k;                 // [2][nfa]
+};
+
+template <int NB>
+__global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = lane_id(), n = A.n, m = A.m, fa = (int)blockIdx.x, slot = (int)blockIdx.y;
+    WaveShared S;
+    S.R = smem; S.n = n; S.m = m; S.kmax = n; S.rcap = n * (n + 1) / 2; S.K = A.Kd; S.kband = A.kband;
+    S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n; S.DtG = S.Dt;
+    S.bstride = n; S.dstride = n; S.dtstride = m; S.brows_global = true; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    Band<NB> bd;
+    load_band<NB>(bd, A.kband, A.lband, lane);
+    // canonical spectrum on the (log-spaced) T2 axis: 15 % at 13 % of the axis, 85 % at 39 % (20 ms and 80 ms on 10..2000 ms)
+    double b = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double u = (double)j / (double)(n - 1), d1 = (u - 0.13) / 0.05, d2 = (u - 0.39) / 0.05;
+        const double xc = 0.15 * exp(-0.5 * d1 * d1) + 0.85 * exp(-0.5 * d2 * d2);
+        if (lane < m) b = fma(S.Dt[(size_t)j * m + lane], xc, b);
+    }
+    b = b / bcast(b, 0);
+    NnlsState<NB> st; st.itmax_hit = 0;
+    MET2_CYC_INIT(st);
+    nnls_reset<NB>(st);
+    project<NB>(S, b, lane, st.h);
+    nnls_solve<NB>(S, bd, st, A.lam[slot], true, lane);
+    const size_t o = ((size_t)slot * A.nfa + fa) * 128;
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        A.x[o + lane + 64 * bb] = st.x[bb];
+        A.pos[o + lane + 64 * bb] = st.pos[bb];
+        A.ord[o + lane + 64 * bb] = st.ord[bb];
+    }
+    if (lane == 0) A.k[(size_t)slot * A.nfa + fa] = (st.itmax_hit == 0) ? st.k : 0;
+}
+
+#ifndef MET2_SEED
+#define MET2_SEED 1            // 0: every voxel grows its first passive set bin by bin from the lambda = 0 solution
+#endif
+template <int NB>
+__device__ __forceinline__ void seed_load(NnlsState<NB> &st, const double *sx, const int *spos, const int *sord, int k, int fa, int lane)
+{
+    const size_t o = (size_t)fa * 128;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        st.x[b] = sx[o + lane + 64 * b]; st.pos[b] = spos[o + lane + 64 * b]; st.ord[b] = sord[o + lane + 64 * b];
+        st.P[b] = ballot(st.pos[b] >= 0);
+    }
+    st.k = k;
+}
+
 // SECOND only gives the second pass of the capacity scheme its own kernel symbol (profilers then list the
 // dominant first pass and the small clean-up pass separately); the code is identical.
 template <int METHOD, int NB, bool STAGE, bool SECOND>
@@ -526,6 +596,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             }
         } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
         S.DtG = A.Dtfa + (size_t)fa * m * n;
+        const int seed_k = (MET2_SEED && A.seed_k) ? A.seed_k[fa] : 0;
+        const bool have_seed = seed_k > 0 && seed_k <= kmax;
         for (int taken = 0; taken <= cnt; ++taken) {
             int slot = taken;
             if (STAGE) {
@@ -558,10 +630,12 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 nnls_solve<NB>(S, bd, st, 0.0, false, lane);
                 const double SSE = sse_of<NB>(S, st, b, lane);
                 const double target = A.x2_factor * SSE;
-                int flag;
+                int flag, nev = 0;
                 double last_x = -1.0, last_sse = 0.0;
                 double lam = fminbound_dev([&](double x) {
+                    if (nev == 0 && have_seed) seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane);
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    ++nev;
                     double SSEr = sse_of<NB>(S, st, b, lane);
                     last_x = x; last_sse = SSEr;
                     return fabs(SSEr - target) / SSE;
@@ -594,9 +668,11 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
                 const double sigma = sqrt(sse_of<NB>(S, st, b, lane) / dof);
                 BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
-                int flag;
+                int flag, nev = 0;
                 double lam = fminbound_dev([&](double x) {
+                    if (nev == 0 && have_seed) seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane);
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    ++nev;
                     return bayes_objective<NB>(S, bd, st, bc, x, b, lane);
                 }, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
@@ -605,9 +681,11 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 regv = lamv = lam;
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
-                int flag, overflow = 0;
+                int flag, overflow = 0, nev = 0;
                 double lam = fminbound_dev([&](double x) {
+                    if (nev == 0 && have_seed) seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane);
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    ++nev;
                     return gcv_objective<NB>(S, bd, st, x, b, lane, overflow);
                 }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
@@ -1233,6 +1311,8 @@ struct met2_plan {
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
     int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;
+    double *dSeedX = nullptr; int *dSeedI = nullptr;      // seed_kernel's output: x [2][nfa][128]; pos | ord [2][nfa][128] each, k [2][nfa]
+    bool seeds_valid = false;
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool timed = false, timed2 = false;
@@ -1588,6 +1668,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMemset(p->dKd, 0, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
+    HIPCHK(hipMalloc(&p->dSeedX, sizeof(double) * 2 * (size_t)n_fa * 128));
+    HIPCHK(hipMalloc(&p->dSeedI, sizeof(int) * (2 * 2 * (size_t)n_fa * 128 + 2 * (size_t)n_fa)));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1616,7 +1698,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus};
+    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeedX, p->dSeedI};
     for (void *b : bufs) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1629,7 +1711,7 @@ static int build_gram(met2_plan *p, hipStream_t s)
 {
     hipLaunchKernelGGL(gram_kernel, dim3(p->n_fa), dim3(256), 0, s, p->n_te, p->n_t2, p->dD, p->dB, p->dDt);
     HIPCHK(hipGetLastError());
-    p->have_dict = true;
+    p->have_dict = true; p->seeds_valid = false;
     return MET2_OK;
 }
 
@@ -1727,7 +1809,7 @@ int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
     HIPCHK(hipMemcpy(p->dKd, K.data(), sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
     p->Lhost.assign(L, L + (size_t)n * n);
     p->log_detL = log(det_lu(n, L));
-    p->have_pen = true;
+    p->have_pen = true; p->seeds_valid = false;
     return MET2_OK;
 }
 
@@ -1865,6 +1947,31 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
     A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
+    A.seed_x = nullptr; A.seed_pos = A.seed_ord = A.seed_k = nullptr;
+    if (!objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG)) {
+        const size_t per = (size_t)p->n_fa * 128;
+        int *spos = p->dSeedI, *sord = p->dSeedI + 2 * per, *sk = p->dSeedI + 4 * per;
+        if (!p->seeds_valid) {
+            SeedArgs SA;
+            SA.n = p->n_t2; SA.m = p->n_te; SA.nfa = p->n_fa;
+            SA.Dfa = p->dD; SA.Bfa = p->dB; SA.Dtfa = p->dDt; SA.kband = p->dKband; SA.lband = p->dLband; SA.Kd = p->dKd;
+            const double gm = 0.5 * (3.0 - sqrt(5.0));
+            SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8);
+            SA.x = p->dSeedX; SA.pos = spos; SA.ord = sord; SA.k = sk;
+            const int lds = (int)sizeof(double) * (p->n_t2 * (p->n_t2 + 1) / 2) + 64;
+            if (g.nb == 1) {
+                HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 2), dim3(64), lds, s, SA);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 2), dim3(64), lds, s, SA);
+            }
+            HIPCHK(hipGetLastError());
+            p->seeds_valid = true;
+        }
+        const int slot = method == MET2_BAYESREG ? 1 : 0;
+        A.seed_x = p->dSeedX + slot * per; A.seed_pos = spos + slot * per; A.seed_ord = sord + slot * per; A.seed_k = sk + (size_t)slot * p->n_fa;
+    }
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }
     rc = launch_method(objgrid ? method + 10 : method, A, g, s);
@@ -1894,6 +2001,7 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
         unsigned long long cy[16];
         HIPCHK(hipMemcpyFromSymbol(cy, HIP_SYMBOL(met2::g_cyc), sizeof(cy)));
         fprintf(stderr, "[met2] gcv trace: gram(mfma)=%llu tridiag=%llu bisect=%llu weights=%llu\n", cy[8], cy[9], cy[10], cy[11]);
+        fprintf(stderr, "[met2] calls: warm solves=%llu duals=%llu append rounds=%llu inner loops after an append=%llu\n", cy[12], cy[13], cy[14], cy[15]);
         fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | slots 5-7 (bayes: chol, upper_times, erf/log; gcv small path: cycles, evaluations, sweeps; append slot += sum k)=%llu %llu %llu\n",
                 cy[0], cy[1], cy[2], cy[3], cy[4], cy[5], cy[6], cy[7]);
 #endif

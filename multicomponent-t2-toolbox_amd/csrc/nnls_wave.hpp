@@ -444,19 +444,23 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
     for (int b = 0; b < NB; ++b) {
         acc[b] = 0.0; acc2[b] = 0.0;
         jc[b] = (unsigned)min(lane + 64 * b, S.n - 1);
-        xp[b] = gatherN<NB>(st.x, st.ord[b]);                            // x by position
     }
     const int k = st.k;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double t = gatherN<NB>(st.x, st.ord[b]);                   // x by position; zero past the set, where ord still
+        xp[b] = (lane + 64 * b < k) ? t : 0.0;                            // names a valid bin: the last group needs no clamping
+    }
 #pragma clang loop unroll(disable)
     for (int p = 0; p < k; p += 4) {
         double v[4][NB], xs[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int pp = min(p + q, k - 1);
+            const int pp = p + q;                                        // <= 64 NB - 1 (p <= k - 1 <= 64 NB - 1 is a multiple of 4)
             const int trow = bcastN_i<NB>(st.ord, pp) * S.bstride;
 #pragma unroll
             for (int b = 0; b < NB; ++b) v[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, trow, jc[b]);
-            xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
+            xs[q] = bcastN<NB>(xp, pp);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -557,6 +561,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
         MET2_CYC_BEGIN(c_du);
         dual<NB>(S, bd, st, lam, lane, w);
         MET2_CYC_END(3, c_du);
+        MET2_CYC_ADD(13, 1);
         if (st.k >= S.kmax) {
             // capacity of the fast path reached: if a variable still wants to enter, the voxel is redone with kmax = n
             double vmax = -1.0;
@@ -591,10 +596,12 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
             MET2_STAT(0, tries + 1);
         }
         MET2_CYC_END(4, c_ap);
+        MET2_CYC_ADD(14, 1);
         if (!accepted) break;
         MET2_CYC_BEGIN(c_in);
         const bool inner_ok = nnls_inner<NB>(S, st, iter, itmax, lane);
         MET2_CYC_END(2, c_in);
+        MET2_CYC_ADD(15, 1);
         if (!inner_ok) { st.itmax_hit |= 1; break; }
         MET2_STAT(2, outer + 1);
         MET2_STAT(3, iter);
@@ -816,6 +823,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
         }
     }
     MET2_CYC_END(1, c_ref);
+    MET2_CYC_ADD(12, 1);
     nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
 }
 
@@ -828,16 +836,16 @@ __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsSt
         // rows of D^T: coalesced, four in flight per step
         double acc = 0.0, acc2 = 0.0, xp[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) xp[b] = gatherN<NB>(st.x, st.ord[b]);
+        for (int b = 0; b < NB; ++b) { const double t = gatherN<NB>(st.x, st.ord[b]); xp[b] = (lane + 64 * b < k) ? t : 0.0; }   // as in dual()
         const unsigned ec = (unsigned)min(lane, S.m - 1);
 #pragma clang loop unroll(disable)
         for (int p = 0; p < k; p += 4) {
             double v[4], xs[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int pp = min(p + q, k - 1);
+                const int pp = p + q;
                 v[q] = ld_row_sel(S.buffer_rows, S.Dt, bcastN_i<NB>(st.ord, pp) * S.dtstride, ec);
-                xs[q] = (p + q < k) ? bcastN<NB>(xp, pp) : 0.0;
+                xs[q] = bcastN<NB>(xp, pp);
             }
             acc = fma(v[0], xs[0], acc); acc2 = fma(v[1], xs[1], acc2);
             acc = fma(v[2], xs[2], acc); acc2 = fma(v[3], xs[3], acc2);
