@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), n = A.n, m = A.m, fa = (int)blockIdx.x, slot = (int)blockIdx.y;
     WaveShared S;
-    S.R = smem; S.n = n; S.m = m; S.kmax = n; S.rcap = n * (n + 1) / 2; S.K = A.Kd; S.kband = A.kband;
+    S.R = smem; S.n = n; S.m = m; S.kmax = n; S.rcap = col_base(n); S.K = A.Kd; S.kband = A.kband;
     S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n; S.DtG = S.Dt;
     S.bstride = n; S.dstride = n; S.dtstride = m; S.brows_global = true; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
     Band<NB> bd;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     const int tri = A.wave_doubles;
     double *sB = smem;
     double *sD = sB + (STAGE ? n * np : 0);
-    double *sR0 = sD + (STAGE ? m * np : 0);
+    double *sR0 = sD + (STAGE ? ((m * np + n * np + 1) & ~1) - n * np : 0);     // the factors start 16-byte aligned
     double *sR = sR0 + (size_t)wave * tri;
     int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
 
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     const int n = A.n, m = A.m, np = A.np;
     double *sB = smem;
     double *sD = sB + (STAGE ? n * np : 0);
-    double *sR0 = sD + (STAGE ? m * np : 0);
+    double *sR0 = sD + (STAGE ? ((m * np + n * np + 1) & ~1) - n * np : 0);     // the factors start 16-byte aligned
     double *sR = sR0 + (size_t)wave * A.wave_doubles;
     int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
     WaveShared S;
@@ -1376,8 +1376,9 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     g.nb = n > 64 ? 2 : 1;
     g.np = n | 1;
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
-    g.wave_doubles = g.kmax * (g.kmax + 1) / 2;
+    g.wave_doubles = col_base(g.kmax);                                 // the factor, columns padded to 16 bytes (nnls_wave.hpp)
     if (method == MET2_GCV && gcv_lds_doubles(m, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(m, n);      // M ((m+1)^2) + vectors + support list
+    g.wave_doubles = (g.wave_doubles + 1) & ~1;                        // every wave's region starts 16-byte aligned
     // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
     // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
     // only ~k rows of B, so the fit kernel prefers the LDS for more resident waves per CU (measured on X2/L2:
@@ -1385,7 +1386,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     // the brute-force FA kernel (cold solves, B-row heavy) stages.
     g.stage = (g.nb == 1 && !allow_unstaged) ? 1 : 0;
     if (const char *e = getenv("MET2_STAGE")) if (allow_unstaged) g.stage = (g.nb == 1 && atoi(e) != 0) ? 1 : 0;
-    const size_t shared = g.stage ? sizeof(double) * ((size_t)n * g.np + (size_t)m * g.np) : 0;
+    const size_t shared = g.stage ? sizeof(double) * ((((size_t)n * g.np + (size_t)m * g.np) + 1) & ~(size_t)1) : 0;
     const size_t per_wave = sizeof(double) * (size_t)g.wave_doubles;
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
@@ -1411,7 +1412,7 @@ static int fast_kmax(const met2_plan *p, int method)
     //  nT2 = 120 with the per-wave queue, where the clean-up pass is cheap: kmax 56 / 64 / 72 / 80 / 96 ->
     //  320 / 464 / 583 / 534 / 391 k voxels/s at 12 / 9 / 7 / 6 / 4 waves per CU)
     int k16 = 8;
-    while (16 * sizeof(double) * (size_t)((k16 + 1) * (k16 + 2) / 2) <= 160 * 1024 - 64) ++k16;
+    while (16 * sizeof(double) * (size_t)col_base(k16 + 1) <= 160 * 1024 - 64) ++k16;
     int k = (3 * p->n_t2 + 4) / 5;
     if (k16 > k) k = k16;
     return k < p->n_t2 ? k : 0;
@@ -1958,7 +1959,7 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
             const double gm = 0.5 * (3.0 - sqrt(5.0));
             SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8);
             SA.x = p->dSeedX; SA.pos = spos; SA.ord = sord; SA.k = sk;
-            const int lds = (int)sizeof(double) * (p->n_t2 * (p->n_t2 + 1) / 2) + 64;
+            const int lds = (int)sizeof(double) * col_base(p->n_t2) + 64;
             if (g.nb == 1) {
                 HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 2), dim3(64), lds, s, SA);
@@ -2054,7 +2055,7 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     const int fa_waves = g.waves >= 16 ? 16 : (g.waves >= 8 ? 8 : g.waves);
     if (g.waves != fa_waves) {
         g.waves = fa_waves; g.block = 64 * fa_waves;
-        g.lds = (int)(sizeof(double) * ((size_t)p->n_t2 * g.np + (size_t)p->n_te * g.np) * (g.stage ? 1 : 0) + sizeof(double) * (size_t)g.wave_doubles * fa_waves + 64);
+        g.lds = (int)(sizeof(double) * ((((size_t)p->n_t2 * g.np + (size_t)p->n_te * g.np) + 1) & ~(size_t)1) * (g.stage ? 1 : 0) + sizeof(double) * (size_t)g.wave_doubles * fa_waves + 64);
     }
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));

@@ -92,7 +92,25 @@ struct NnlsState {
 };
 
 __device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // row-packed factors of objectives.hpp: entry (i,c) at row_base + c
-__device__ __forceinline__ int col_base(int c) { return (c * (c + 1)) >> 1; }                          // the solver's factor: entry (r,c) at col_base(c) + r
+// the solver's factor: entry (r,c) at col_base(c) + r.  Every column starts on an even index (16 bytes): the sweeps that read
+// four consecutive rows of a column then use two ds_read_b128 (4 LDS cycles each) instead of two ds_read2_b64 (8 each) -- the
+// LDS array was busy 53 % of the X2 kernel's cycles with the unpadded layout (SQ_LDS_IDX_ACTIVE, profiles/r02m_config1_pmc.csv)
+__host__ __device__ __forceinline__ constexpr int col_len(int c) { return (c + 2) & ~1; }                  // entries 0..c, padded to even
+__host__ __device__ __forceinline__ constexpr int col_base(int c) { return ((c * (c + 1)) >> 1) + ((c + 1) >> 1); }   // sum of col_len below c
+
+// four / two consecutive doubles from a 16-byte aligned LDS address (ds_read_b128)
+typedef double met2_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_quad(const double *p, double &a, double &b, double &c, double &d)
+{
+    const met2_d2 *q = (const met2_d2 *)__builtin_assume_aligned(p, 16);
+    const met2_d2 u = q[0], v = q[1];
+    a = u.x; b = u.y; c = v.x; d = v.y;
+}
+__device__ __forceinline__ void lds_pair(const double *p, double &a, double &b)
+{
+    const met2_d2 u = *(const met2_d2 *)__builtin_assume_aligned(p, 16);
+    a = u.x; b = u.y;
+}
 
 // ---- NB-aware cross-lane helpers (idx / src index bins or positions 0..64*NB-1) ----
 template <int NB>
@@ -245,7 +263,7 @@ __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<
     }
     int c = k - 1;
     for (; c >= 1; c -= 2) {
-        const int cb1 = cb - c, cb2 = cb1 - (c - 1);                    // col_base(c-1), col_base(c-2)
+        const int cb1 = cb - col_len(c - 1), cb2 = cb1 - col_len(c - 2);   // col_base(c-1), col_base(c-2)
 #pragma unroll
         for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rb[b] = (pl < c - 1) ? S.R[cb1 + pl] : 0.0; }   // column c-1
         {
@@ -286,7 +304,7 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int pl = lane + 64 * b;
-                v[b] = (pl >= p && pl <= k - 2) ? S.R[cbl[b] + pl + 1 + i] : 0.0;       // col_base(pl+1) = col_base(pl) + pl + 1
+                v[b] = (pl >= p && pl <= k - 2) ? S.R[cbl[b] + col_len(pl) + i] : 0.0;   // col_base(pl+1) = col_base(pl) + col_len(pl)
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -321,9 +339,9 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
                 const int pl = lane + 64 * b;
                 double nv = c * carry[b] + s * rowj[b];
                 carry[b] = -s * carry[b] + c * rowj[b];
-                // new entry (j-1, pl-1): col_base(pl-1) = col_base(pl) - pl
-                if (pl > j && pl < k) S.R[cbl[b] - pl + j - 1] = nv;
-                if (pl == j) S.R[cbl[b] - pl + j - 1] = sig;
+                // new entry (j-1, pl-1): col_base(pl-1) = col_base(pl) - col_len(pl-1)
+                if (pl > j && pl < k) S.R[cbl[b] - col_len(pl - 1) + j - 1] = nv;
+                if (pl == j) S.R[cbl[b] - col_len(pl - 1) + j - 1] = sig;
                 if (pl == j - 1) { st.y[b] = ynew; st.rinv[b] = sinv; }
             }
         }
@@ -694,16 +712,17 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
 #pragma unroll
             for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); }
         }
-        const double *ci = S.R + cbi, *cj = ci + i + 1;                 // columns i and i + 1
+        const double *ci = S.R + cbi, *cj = ci + col_len(i);            // columns i and i + 1
         int j = 0;
 #pragma clang loop unroll(disable)
         for (; j + 4 <= i; j += 4) {                                    // four rows above per step: the three LDS pointers are bumped once per eight FMAs
-            const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
-            const double u0 = cj[j], u1 = cj[j + 1], u2 = cj[j + 2], u3 = cj[j + 3];
+            double s0, s1, s2, s3, u0, u1, u2, u3;                      // j is a multiple of 4 and every column starts 16-byte aligned
+            lds_quad(ci + j, s0, s1, s2, s3);
+            lds_quad(cj + j, u0, u1, u2, u3);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const double *cc = S.R + cbc[b] + j;
-                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                double q0, q1, q2, q3;
+                lds_quad(S.R + cbc[b] + j, q0, q1, q2, q3);
                 a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);      // the two rows are the two independent chains
                 a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
                 a[b] = fma(-s2, q2, a[b]); c[b] = fma(-u2, q2, c[b]);
@@ -711,12 +730,13 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
             }
         }
         if (j + 2 <= i) {                                               // two rows above (one ds_read2 per column)
-            const double s0 = ci[j], s1 = ci[j + 1];
-            const double u0 = cj[j], u1 = cj[j + 1];
+            double s0, s1, u0, u1;
+            lds_pair(ci + j, s0, s1);
+            lds_pair(cj + j, u0, u1);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const double *cc = S.R + cbc[b] + j;
-                const double q0 = cc[0], q1 = cc[1];
+                double q0, q1;
+                lds_pair(S.R + cbc[b] + j, q0, q1);
                 a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);
                 a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
             }
@@ -734,7 +754,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         for (int b = 0; b < NB; ++b) c[b] = fma(-sr, r[b], c[b]);
         finish(i + 1, c, r1);
         __builtin_amdgcn_wave_barrier();
-        cbi += 2 * i + 3;                                               // col_base(i + 2) - col_base(i)
+        cbi += col_len(i) + col_len(i + 1);                             // col_base(i + 2) - col_base(i)
     }
     if (i < k) {                                                        // odd k: the last row on its own
         double a[NB], a2[NB];
@@ -749,11 +769,12 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         int j = 0;
 #pragma clang loop unroll(disable)
         for (; j + 4 <= i; j += 4) {
-            const double s0 = ci[j], s1 = ci[j + 1], s2 = ci[j + 2], s3 = ci[j + 3];
+            double s0, s1, s2, s3;
+            lds_quad(ci + j, s0, s1, s2, s3);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const double *cc = S.R + cbc[b] + j;
-                const double q0 = cc[0], q1 = cc[1], q2 = cc[2], q3 = cc[3];
+                double q0, q1, q2, q3;
+                lds_quad(S.R + cbc[b] + j, q0, q1, q2, q3);
                 a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
                 a[b] = fma(-s2, q2, a[b]); a2[b] = fma(-s3, q3, a2[b]);
             }

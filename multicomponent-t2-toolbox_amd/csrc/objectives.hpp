@@ -68,7 +68,7 @@ __device__ __forceinline__ bool chol_full_rowwise(const WaveShared &S, const Ban
         }
         fetch(j + 2, gb0, gk0);
         fetch(j + 3, gb1, gk1);
-        const double *cj = S.R + cbj, *cj1 = cj + j + 1;                // columns j and j + 1
+        const double *cj = S.R + cbj, *cj1 = cj + col_len(j);           // columns j and j + 1
         int k = 0;
 #pragma clang loop unroll(disable)
         for (; k + 2 <= j; k += 2) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ bool chol_full_rowwise(const WaveShared &S, const Ban
         for (int b = 0; b < NB; ++b) c[b] = fma(-su, u[b], c[b]);
         if (!finish(j + 1, c, w)) return false;
         __builtin_amdgcn_wave_barrier();
-        cbj += 2 * j + 3;
+        cbj += col_len(j) + col_len(j + 1);
     }
     if (j < n) {                                                        // odd n: the last row on its own
         double a[NB], u[NB];
@@ -180,11 +180,13 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
             const double *cr = S.R + col_base(r);                     // column r: U[j][r], j < r
             int j = r0;
             for (; j + 2 <= r; j += 2) {
-                const double s0 = cr[j], s1 = cr[j + 1];
+                double s0, s1;                                        // j is even and every column starts 16-byte aligned
+                lds_pair(cr + j, s0, s1);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const double *cc = S.R + cbc[b] + j;
-                    a[b] = fma(-s0, cc[0], a[b]); a2[b] = fma(-s1, cc[1], a2[b]);
+                    double q0, q1;
+                    lds_pair(S.R + cbc[b] + j, q0, q1);
+                    a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
                 }
             }
             if (j < r) {
@@ -268,7 +270,7 @@ __device__ __forceinline__ void upper_times(const WaveShared &S, const double (&
             double u = (i <= j) ? S.R[cbj + i] : 0.0;                   // column j: rows 0..j
             out[b] = fma(u, fj, out[b]);
         }
-        cbj += j + 1;
+        cbj += col_len(j);
     }
 }
 
