@@ -634,6 +634,9 @@ __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
     st.k = 0;
 }
 
+// Row-by-row form of the refactorisation: every row sums over ALL rows above it.  Used at one bin per lane (k <= 64), where it
+// is the faster of the two (X2/L2 on configs[1]: 152.9 ms against 165.3 ms for the blocked form below: with at most four
+// trailing tiles the blocked form saves little arithmetic and exposes the latency of its gather phase).
 // Rebuild R, 1/diag and y = R^-T h_P for the CURRENT passive set and pivot order at a new lambda.
 // Row-by-row (left-looking) Cholesky: row i of R is  (G[ord_i][ord_c] - sum_{j<i} R[j][i] R[j][c]) / R[i][i]  with
 // lane <-> column c, so a row costs i independent LDS row reads + FMAs (issued four at a time) instead of the i
@@ -643,7 +646,7 @@ __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 // Returns false -- R is then unusable, ord/pos/P/k/x are untouched -- when a pivot falls under the independence
 // threshold of try_append; the caller re-appends column by column, which drops such columns.
 template <int NB>
-__device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
+__device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
     const int k = st.k, n = S.n;
     int cbl[NB], cbc[NB];
@@ -809,6 +812,236 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
         st.y[b] = (pl < k) ? g[b] * ri : st.y[b];
     }
     return true;
+}
+
+typedef double met2_d4 __attribute__((ext_vector_type(4)));
+
+// Rebuild R, 1/diag and y = R^-T h_P for the CURRENT passive set and pivot order at a new lambda: blocked right-looking
+// Cholesky of A = G_PP (G = B + lam K, rows and columns in pivot order) in the packed LDS triangle.
+//   (0) A's upper triangle is gathered into LDS, four pivots' rows of B and K in flight;
+//   per block row of 16 pivots:
+//   (a) its rows are finished two at a time, lane <-> column, with inner products over the rows of the block only (<= 15
+//       terms: everything above the block has been subtracted by the trailing updates), y by one elimination step per row;
+//   (b) every trailing 16 x 16 tile C(ti, tj), ti <= tj, takes C -= R(block, ti)^T R(block, tj) as four v_mfma_f64_16x16x4
+//       (operands one f64 per lane from the packed columns, accumulator = the tile).
+// Used at two bins per lane (k up to 128), where the row-by-row form's sums get long: the brute-force-FA GCV pipeline of
+// configs[4] 220 -> 225 k voxels/s.
+// Returns false -- R is then unusable, ord/pos/P/k/x are untouched -- when a pivot falls under the independence
+// threshold of try_append; the caller re-appends column by column, which drops such columns.
+template <int NB>
+__device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
+{
+    const int k = st.k, n = S.n;
+    int cbl[NB], cbc[NB];
+    unsigned jc[NB];
+    double g[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        cbl[b] = col_base(pl);
+        cbc[b] = col_base(min(pl, k - 1));                              // an existing column for the unpredicated reads
+        jc[b] = (unsigned)min(pl, n - 1);
+        const double hh = gatherN<NB>(st.h, st.ord[b]);
+        g[b] = (pl < k) ? hh : 0.0;
+    }
+    // diagonal of G at the passive bins, by position (for the test after the sweep)
+    double gdp[NB];
+    {
+        double gdb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double bd0 = S.have_bdiag ? S.bdiag[b] : S.B[jc[b] * S.bstride + jc[b]];
+            gdb[b] = (lam != 0.0) ? fma(lam, S.K[jc[b] * n + jc[b]], bd0) : bd0;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gdp[b] = gatherN<NB>(gdb, st.ord[b]);
+    }
+    // ---- (0) A into LDS.  Positions past the set still name valid bins (their rows are loaded and dropped).
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < k; i += 4) {
+        double vb[4][NB], vk[4][NB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = bcastN_i<NB>(st.ord, i + q);                  // i + q <= 64 NB - 1 (i is a multiple of 4 below k <= 64 NB)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                vb[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, t * S.bstride, jc[b]);
+                vk[q][b] = (lam != 0.0) ? ld_row_sel(S.buffer_rows, S.K, t * n, jc[b]) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double t0[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) t0[b] = fma(lam, vk[q][b], vb[q][b]);     // G[ord_{i+q}][.] by bin
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int pl = lane + 64 * b;
+                const double av = gatherN<NB>(t0, st.ord[b]);                       // by position
+                if (i + q < k && pl >= i + q && pl < k) S.R[cbl[b] + i + q] = av;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // finish a row: a holds A[i][c] - sum_{j<i} R[j][i] R[j][c]; scale, store column entries, one elimination step for y
+    // (the independence test of the pivots is done for all rows at once after the sweep: a non-positive or NaN pivot only
+    //  poisons the rows below it, and the whole factor is discarded then)
+    auto finish = [&](int i, double (&a)[NB], double (&r)[NB]) {
+        const double d = bcastN<NB>(a, i);
+        const double rinv = rsqrt_nr(d);
+        const double yi = bcastN<NB>(g, i) * rinv;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int pl = lane + 64 * b;
+            r[b] = a[b] * rinv;                                         // lane i: d * rinv = R[i][i]
+            if (pl >= i && pl < k) S.R[cbl[b] + i] = r[b];
+            g[b] = (pl > i) ? fma(-r[b], yi, g[b]) : g[b];
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    const int nt = (k + 15) >> 4;
+    for (int kb = 0; kb < nt; ++kb) {
+        const int r0 = 16 * kb, r1 = min(k, r0 + 16);
+        int cbi = col_base(r0);
+        int i = r0;
+        // ---- (a) rows i and i + 1 together: they share the reads of the block's rows above them, and row i + 1 takes
+        //      row i's contribution from registers
+        for (; i + 1 < r1; i += 2) {
+            double a[NB], c[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int pl = lane + 64 * b;
+                double a0, c0;
+                lds_pair(S.R + cbc[b] + i, a0, c0);                     // rows i, i + 1 of the lane's column (i is even)
+                a[b] = (pl >= i && pl < k) ? a0 : 0.0;
+                c[b] = (pl > i && pl < k) ? c0 : 0.0;
+            }
+            const double *ci = S.R + cbi, *cj = ci + col_len(i);        // columns i and i + 1
+            int j = r0;
+#pragma clang loop unroll(disable)
+            for (; j + 4 <= i; j += 4) {
+                double s0, s1, s2, s3, u0, u1, u2, u3;                  // j is a multiple of 4 and every column starts 16-byte aligned
+                lds_quad(ci + j, s0, s1, s2, s3);
+                lds_quad(cj + j, u0, u1, u2, u3);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1, q2, q3;
+                    lds_quad(S.R + cbc[b] + j, q0, q1, q2, q3);
+                    a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);  // the two rows are the two independent chains
+                    a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
+                    a[b] = fma(-s2, q2, a[b]); c[b] = fma(-u2, q2, c[b]);
+                    a[b] = fma(-s3, q3, a[b]); c[b] = fma(-u3, q3, c[b]);
+                }
+            }
+            if (j < i) {                                                // i - r0 is even: two rows left
+                double s0, s1, u0, u1;
+                lds_pair(ci + j, s0, s1);
+                lds_pair(cj + j, u0, u1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1;
+                    lds_pair(S.R + cbc[b] + j, q0, q1);
+                    a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);
+                    a[b] = fma(-s1, q1, a[b]); c[b] = fma(-u1, q1, c[b]);
+                }
+            }
+            double r[NB], r2[NB];
+            finish(i, a, r);
+            const double sr = bcastN<NB>(r, i + 1);                     // R[i][i+1]
+#pragma unroll
+            for (int b = 0; b < NB; ++b) c[b] = fma(-sr, r[b], c[b]);
+            finish(i + 1, c, r2);
+            __builtin_amdgcn_wave_barrier();
+            cbi += col_len(i) + col_len(i + 1);
+        }
+        if (i < r1) {                                                   // odd k: the last row on its own
+            double a[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; const double a0 = S.R[cbc[b] + i]; a[b] = (pl >= i && pl < k) ? a0 : 0.0; }
+            const double *ci = S.R + cbi;
+            int j = r0;
+#pragma clang loop unroll(disable)
+            for (; j + 2 <= i; j += 2) {
+                double s0, s1;
+                lds_pair(ci + j, s0, s1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1;
+                    lds_pair(S.R + cbc[b] + j, q0, q1);
+                    a[b] = fma(-s0, q0, a[b]);
+                    a[b] = fma(-s1, q1, a[b]);
+                }
+            }
+            double r[NB];
+            finish(i, a, r);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- (b) trailing tiles on the matrix cores (only a full block has columns behind it)
+        for (int ti = kb + 1; ti < nt; ++ti) {
+            const int ca = 16 * ti + li;                                // this lane's column inside tile column ti
+            const int cba = col_base(min(ca, k - 1));
+            double aop[4];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const double v = S.R[cba + r0 + 4 * sidx + lk];
+                aop[sidx] = (ca < k) ? -v : 0.0;
+            }
+            for (int tj = ti; tj < nt; ++tj) {
+                const int cc = 16 * tj + li;
+                const int cbb = col_base(min(cc, k - 1));
+                double bop[4];
+                met2_d4 acc;
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const double v = S.R[cbb + r0 + 4 * sidx + lk];
+                    bop[sidx] = (cc < k) ? v : 0.0;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * ti + lk + 4 * v;
+                    acc[v] = (cc < k && row <= cc) ? S.R[cbb + row] : 0.0;
+                }
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sidx], bop[sidx], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * ti + lk + 4 * v;
+                    if (cc < k && row <= cc) S.R[cbb + row] = acc[v];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // lane p: R[p][p]; its square is the pivot the row was scaled with: all pivots against the independence threshold of
+    // try_append at once (NaN from a negative pivot fails the comparison too)
+    bool bad = false;
+    double dgl[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        dgl[b] = (pl < k) ? S.R[cbl[b] + pl] : 1.0;
+        bad = bad || (ballot((pl < k) && !(dgl[b] * dgl[b] > 1e-14 * gdp[b])) != 0ull);
+    }
+    if (bad) return false;
+    // lane p: 1 / R[p][p] and y_p = g_p / R[p][p] (g_p is final once rows < p are eliminated)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        const double ri = rcp_nr(dgl[b]);
+        st.rinv[b] = (pl < k) ? ri : st.rinv[b];
+        st.y[b] = (pl < k) ? g[b] * ri : st.y[b];
+    }
+    return true;
+}
+
+#ifndef MET2_REFACTOR_BLOCKED_FROM
+#define MET2_REFACTOR_BLOCKED_FROM 2        // bins per lane from which the blocked form is used
+#endif
+template <int NB>
+__device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
+{
+    if (NB >= MET2_REFACTOR_BLOCKED_FROM) return refactor_blocked<NB>(S, bd, st, lam, lane);
+    return refactor_rowwise<NB>(S, bd, st, lam, lane);
 }
 
 // cold-start solve; on return st.x is the solution

@@ -118,7 +118,6 @@ __device__ __forceinline__ bool chol_full_rowwise(const WaveShared &S, const Ban
     return true;
 }
 
-typedef double met2_d4 __attribute__((ext_vector_type(4)));
 
 // The same factor by a blocked right-looking Cholesky with the trailing update on the matrix cores (the default; the row-wise
 // routine above stays behind -DMET2_CHOL_ROWWISE for A/B runs).  A = beta B + beta lam K is first written into the wave's
