@@ -466,15 +466,15 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 // changes; every voxel's first evaluation starts from that passive set and iterate: one refactorisation and a few exchanges.
 // Any x >= 0 is a feasible start for Lawson-Hanson and the regularised problem is strictly convex, so the solution is the
 // cold-start one up to rounding, and because the seed depends on the plan only, a voxel's result stays independent of its
-// neighbours and of the order of the voxel list.  The lambda = 0 solves keep the cold path: x(0) need not be unique and NNLS,
+// neighbours and of the order of the voxel list.  T2SPARC's single solve at its fixed lambda is seeded the same way.  The lambda = 0 solves keep the cold path: x(0) need not be unique and NNLS,
 // the L-curve and BayesReg's degrees of freedom use x(0) itself.
 struct SeedArgs {
     int n, m, nfa;
     const double *Dfa, *Bfa, *Dtfa, *kband, *lband, *Kd;
-    double lam[2];          // slot 0: X2 and GCV (bounds 0 / 1e-8 .. 10), slot 1: BayesReg (1e-8 .. 2)
-    double *x;              // [2][nfa][128]  bin-indexed iterate
-    int *pos, *ord;         // [2][nfa][128]  bin -> position (-1 outside the set), position -> bin
-    int *k;                 // [2][nfa]
+    double lam[3];          // slot 0: X2 and GCV (bounds 0 / 1e-8 .. 10), slot 1: BayesReg (1e-8 .. 2), slot 2: T2SPARC's fixed lambda
+    double *x;              // [3][nfa][128]  bin-indexed iterate
+    int *pos, *ord;         // [3][nfa][128]  bin -> position (-1 outside the set), position -> bin
+    int *k;                 // [3][nfa]
 };
 
 template <int NB>
@@ -623,7 +623,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             if (METHOD == MET2_NNLS) {
                 nnls_solve<NB>(S, bd, st, 0.0, false, lane);
             } else if (METHOD == MET2_T2SPARC) {
-                nnls_solve<NB>(S, bd, st, A.t2sparc_lambda, true, lane);
+                if (have_seed) { seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane); nnls_solve_warm<NB>(S, bd, st, A.t2sparc_lambda, true, lane); }
+                else nnls_solve<NB>(S, bd, st, A.t2sparc_lambda, true, lane);
                 regv = lamv = A.t2sparc_lambda;
             } else if (METHOD == MET2_X2) {
                 // algorithms.py:211-233
@@ -1311,8 +1312,8 @@ struct met2_plan {
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
     int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;
-    double *dSeedX = nullptr; int *dSeedI = nullptr;      // seed_kernel's output: x [2][nfa][128]; pos | ord [2][nfa][128] each, k [2][nfa]
-    bool seeds_valid = false;
+    double *dSeedX = nullptr; int *dSeedI = nullptr;      // seed_kernel's output: x [3][nfa][128]; pos | ord [3][nfa][128] each, k [3][nfa]
+    bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool timed = false, timed2 = false;
@@ -1669,8 +1670,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMemset(p->dKd, 0, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
-    HIPCHK(hipMalloc(&p->dSeedX, sizeof(double) * 2 * (size_t)n_fa * 128));
-    HIPCHK(hipMalloc(&p->dSeedI, sizeof(int) * (2 * 2 * (size_t)n_fa * 128 + 2 * (size_t)n_fa)));
+    HIPCHK(hipMalloc(&p->dSeedX, sizeof(double) * 3 * (size_t)n_fa * 128));
+    HIPCHK(hipMalloc(&p->dSeedI, sizeof(int) * (2 * 3 * (size_t)n_fa * 128 + 3 * (size_t)n_fa)));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1949,28 +1950,28 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     A.seed_x = nullptr; A.seed_pos = A.seed_ord = A.seed_k = nullptr;
-    if (!objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG)) {
+    if (!objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
         const size_t per = (size_t)p->n_fa * 128;
-        int *spos = p->dSeedI, *sord = p->dSeedI + 2 * per, *sk = p->dSeedI + 4 * per;
-        if (!p->seeds_valid) {
+        int *spos = p->dSeedI, *sord = p->dSeedI + 3 * per, *sk = p->dSeedI + 6 * per;
+        if (!p->seeds_valid || p->seeds_t2sparc != p->opt.t2sparc_lambda) {
             SeedArgs SA;
             SA.n = p->n_t2; SA.m = p->n_te; SA.nfa = p->n_fa;
             SA.Dfa = p->dD; SA.Bfa = p->dB; SA.Dtfa = p->dDt; SA.kband = p->dKband; SA.lband = p->dLband; SA.Kd = p->dKd;
             const double gm = 0.5 * (3.0 - sqrt(5.0));
-            SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8);
+            SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8); SA.lam[2] = p->opt.t2sparc_lambda;
             SA.x = p->dSeedX; SA.pos = spos; SA.ord = sord; SA.k = sk;
             const int lds = (int)sizeof(double) * col_base(p->n_t2) + 64;
             if (g.nb == 1) {
                 HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 2), dim3(64), lds, s, SA);
+                hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
             } else {
                 HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 2), dim3(64), lds, s, SA);
+                hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
             }
             HIPCHK(hipGetLastError());
-            p->seeds_valid = true;
+            p->seeds_valid = true; p->seeds_t2sparc = p->opt.t2sparc_lambda;
         }
-        const int slot = method == MET2_BAYESREG ? 1 : 0;
+        const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : 0);
         A.seed_x = p->dSeedX + slot * per; A.seed_pos = spos + slot * per; A.seed_ord = sord + slot * per; A.seed_k = sk + (size_t)slot * p->n_fa;
     }
     HIPCHK(hipEventRecord(p->ev0, s));
