@@ -341,8 +341,12 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 
 // LDS doubles a wave needs for it: M (n rows of stride np, three zero padding columns for the 4-wide loops), two padded
 // Householder vectors and the support list
-__host__ __device__ inline int gcv_row_stride(int m) { return (m + 1 + 3) | 1; }
-__host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = m + 1; return n * gcv_row_stride(m) + 2 * (n + 3) + (kcap + 1) / 2 + 2; }
+// Row stride of M: >= n + 3 (the four-wide sweeps run into zero padding), even (every row 16-byte aligned: the sweeps read and
+// write with ds_read/write_b128) and = 2 mod 4: then the 16 lanes of a b128 lane group, each on its own row, fall on 16
+// different four-dword bank groups (2 np mod 64 is an odd multiple of 4) -- conflict-free.
+__host__ __device__ inline int gcv_row_stride(int m) { int np = m + 4; while ((np & 3) != 2) ++np; return np; }
+__host__ __device__ inline int gcv_vec_len(int m) { return (m + 4 + 1) & ~1; }          // n + 3 entries, padded to even
+__host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = m + 1; return n * gcv_row_stride(m) + 2 * gcv_vec_len(m) + (kcap + 1) / 2 + 2; }
 
 // Sturm count: number of eigenvalues < x (<= x up to the measure-zero case of an exactly vanishing minor) of the symmetric
 // tridiagonal matrix given as (d_j, e_{j-1}^2) pairs, by the sign changes of the leading principal minors
@@ -401,7 +405,7 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     const int m = S.m, n = m + 1, np = gcv_row_stride(m);
     double *M = S.R;                         // [n][np], row a of lane a; row/column 0 = the sqrt(c) row of E
     double *vb = M + n * np;                 // [n + 3] Householder vector, zero padded
-    double *wb = vb + n + 3;                 // [n + 3]
+    double *wb = vb + gcv_vec_len(m);        // [n + 3]
     // ---- 1. M = A A^T on the matrix cores
     {
         const int li = lane & 15, lk = lane >> 4;
@@ -459,9 +463,12 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
         if (lane < n) vb[lane] = v;
         __builtin_amdgcn_wave_barrier();
         double p = 0.0, p2 = 0.0;
-        for (int b = j + 1; b < n; b += 4) {                          // may run into the zero padding
-            const double m0 = Mrow[b], m1 = Mrow[b + 1], m2 = Mrow[b + 2], m3 = Mrow[b + 3];
-            const double u0 = vb[b], u1 = vb[b + 1], u2 = vb[b + 2], u3 = vb[b + 3];
+        const int b0 = (j + 1) & ~3;                                  // 16-byte aligned start: the up to three columns <= j it takes in have v = w = 0
+#pragma unroll 2
+        for (int b = b0; b < n; b += 4) {                             // may run into the zero padding
+            double m0, m1, m2, m3, u0, u1, u2, u3;
+            lds_quad(Mrow + b, m0, m1, m2, m3);
+            lds_quad(vb + b, u0, u1, u2, u3);
             p = fma(m0, u0, p); p2 = fma(m1, u1, p2); p = fma(m2, u2, p); p2 = fma(m3, u3, p2);
         }
         p = below ? tau * (p + p2) : 0.0;
@@ -470,14 +477,17 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
         if (lane < n) wb[lane] = w;
         __builtin_amdgcn_wave_barrier();
         if (below) {
-            for (int b = j + 1; b < n; b += 4) {
-                const double m0 = Mrow[b], m1 = Mrow[b + 1], m2 = Mrow[b + 2], m3 = Mrow[b + 3];
-                const double u0 = vb[b], u1 = vb[b + 1], u2 = vb[b + 2], u3 = vb[b + 3];
-                const double q0 = wb[b], q1 = wb[b + 1], q2 = wb[b + 2], q3 = wb[b + 3];
-                Mrow[b] = fma(-w, u0, fma(-v, q0, m0));
-                Mrow[b + 1] = fma(-w, u1, fma(-v, q1, m1));
-                Mrow[b + 2] = fma(-w, u2, fma(-v, q2, m2));
-                Mrow[b + 3] = fma(-w, u3, fma(-v, q3, m3));
+#pragma unroll 2
+            for (int b = b0; b < n; b += 4) {
+                double m0, m1, m2, m3, u0, u1, u2, u3, q0, q1, q2, q3;
+                lds_quad(Mrow + b, m0, m1, m2, m3);
+                lds_quad(vb + b, u0, u1, u2, u3);
+                lds_quad(wb + b, q0, q1, q2, q3);
+                met2_d2 *dst = (met2_d2 *)__builtin_assume_aligned(Mrow + b, 16);
+                met2_d2 o0, o1;
+                o0.x = fma(-w, u0, fma(-v, q0, m0)); o0.y = fma(-w, u1, fma(-v, q1, m1));
+                o1.x = fma(-w, u2, fma(-v, q2, m2)); o1.y = fma(-w, u3, fma(-v, q3, m3));
+                dst[0] = o0; dst[1] = o1;
             }
         }
         if (lane == j) ej = alpha;
@@ -559,7 +569,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     if (gcv_lds_doubles(m, k) > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
     // support list (ascending bins) behind the matrices in the wave's LDS region
-    int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 2 * (m + 1 + 3));
+    int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 2 * gcv_vec_len(m));
     int base = 0;
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
