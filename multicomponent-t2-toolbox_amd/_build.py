@@ -9,6 +9,11 @@ LIB = os.path.join(HERE, "libmet2_hip.so")
 SOURCES = ["met2_hip.hip"]
 HEADERS = ["wave_ops.hpp", "nnls_wave.hpp", "objectives.hpp", os.path.join("..", "..", "include", "met2_hip.h")]
 STAMP = LIB + ".flags"          # extra compile flags the library was built with (MET2_BUILD_DEFINES, e.g. -DMET2_CYCSTATS)
+# Machine LICM off: it hoists the materialisation of fp64 literals (erf/log coefficients of the BayesReg objective, 20 register
+# pairs) and per-lane address constants out of the voxel loop, runs out of registers and spills them to scratch -- BayesReg at
+# 32 x 60 reloaded 110 KB per voxel from scratch.  Without it: 59 -> 2 spilled VGPRs there, configs[3] 2.77 -> 2.95 M voxels/s,
+# configs[2] +2.7 %, configs[1] unchanged, X2 at 48 x 120 -2 %.
+CODEGEN = ["-mllvm", "-disable-machine-licm"]
 
 
 def hipcc():
@@ -29,14 +34,14 @@ def stale():
     if built_with != extra_flags():
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra_flags() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + CODEGEN + extra_flags() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

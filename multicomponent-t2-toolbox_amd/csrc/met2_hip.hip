@@ -19,6 +19,7 @@
 //   metrics_kernel          motor:443-472 standalone
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -260,8 +261,7 @@ struct FitArgs {
     double *fsol, *sig, *reg, *lam, *maps;
     int32_t *status;
     int64_t nvox;
-    const double *seed_x;                 // [nfa][128] first-Brent-point seeds of the method (seed_kernel), or NULL
-    const int *seed_pos, *seed_ord, *seed_k;
+    const char *seed;                     // [nfa] SeedRec: first-Brent-point seeds of the method (seed_kernel), or NULL
 };
 
 // SciPy's bounded Brent (scipy.optimize.fminbound, called at algorithms.py:219,280 and
@@ -472,9 +472,14 @@ struct SeedArgs {
     int n, m, nfa;
     const double *Dfa, *Bfa, *Dtfa, *kband, *lband, *Kd;
     double lam[3];          // slot 0: X2 and GCV (bounds 0 / 1e-8 .. 10), slot 1: BayesReg (1e-8 .. 2), slot 2: T2SPARC's fixed lambda
-    double *x;              // [3][nfa][128]  bin-indexed iterate
-    int *pos, *ord;         // [3][nfa][128]  bin -> position (-1 outside the set), position -> bin
-    int *k;                 // [3][nfa]
+    char *out;              // [3][nfa] SeedRec
+};
+// one record per (slot, flip angle): a single kernel-argument pointer reaches all of it (the fit kernels are short of SGPRs)
+struct SeedRec {
+    double x[128];          // bin-indexed iterate
+    int pos[128];           // bin -> position (-1 outside the set)
+    int ord[128];           // position -> bin
+    int k, pad[3];
 };
 
 template <int NB>
@@ -501,26 +506,33 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
     nnls_reset<NB>(st);
     project<NB>(S, b, lane, st.h);
     nnls_solve<NB>(S, bd, st, A.lam[slot], true, lane);
-    const size_t o = ((size_t)slot * A.nfa + fa) * 128;
+    SeedRec *rec = (SeedRec *)A.out + ((size_t)slot * A.nfa + fa);
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
-        A.x[o + lane + 64 * bb] = st.x[bb];
-        A.pos[o + lane + 64 * bb] = st.pos[bb];
-        A.ord[o + lane + 64 * bb] = st.ord[bb];
+        rec->x[lane + 64 * bb] = st.x[bb];
+        rec->pos[lane + 64 * bb] = st.pos[bb];
+        rec->ord[lane + 64 * bb] = st.ord[bb];
     }
-    if (lane == 0) A.k[(size_t)slot * A.nfa + fa] = (st.itmax_hit == 0) ? st.k : 0;
+    if (lane == 0) rec->k = (st.itmax_hit == 0) ? st.k : 0;
 }
 
 #ifndef MET2_SEED
 #define MET2_SEED 1            // 0: every voxel grows its first passive set bin by bin from the lambda = 0 solution
 #endif
 template <int NB>
-__device__ __forceinline__ void seed_load(NnlsState<NB> &st, const double *sx, const int *spos, const int *sord, int k, int fa, int lane)
+__device__ __forceinline__ void seed_load(NnlsState<NB> &st, const char *seed, int k, int fa, int lane)
 {
-    const size_t o = (size_t)fa * 128;
+    // raw buffer loads: the record's offset travels in a scalar register, the lane part is a 32-bit offset (plain indexing made
+    // the compiler keep two 64-bit per-lane record addresses per chunk, and spill them)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)seed, 0, 0x40000000, 0x00020000);
+    const unsigned rec = (unsigned)fa * (unsigned)sizeof(SeedRec);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        st.x[b] = sx[o + lane + 64 * b]; st.pos[b] = spos[o + lane + 64 * b]; st.ord[b] = sord[o + lane + 64 * b];
+        const unsigned e = (unsigned)(lane + 64 * b);
+        const auto xv = __builtin_amdgcn_raw_buffer_load_b64(r, 8u * e, rec, 0);
+        st.x[b] = __hiloint2double((int)xv[1], (int)xv[0]);
+        st.pos[b] = (int)__builtin_amdgcn_raw_buffer_load_b32(r, 4u * e, rec + (unsigned)offsetof(SeedRec, pos), 0);
+        st.ord[b] = (int)__builtin_amdgcn_raw_buffer_load_b32(r, 4u * e, rec + (unsigned)offsetof(SeedRec, ord), 0);
         st.P[b] = ballot(st.pos[b] >= 0);
     }
     st.k = k;
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             }
         } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
         S.DtG = A.Dtfa + (size_t)fa * m * n;
-        const int seed_k = (MET2_SEED && A.seed_k) ? A.seed_k[fa] : 0;
+        const int seed_k = (MET2_SEED && A.seed) ? ((const SeedRec *)A.seed)[fa].k : 0;
         const bool have_seed = seed_k > 0 && seed_k <= kmax;
         for (int taken = 0; taken <= cnt; ++taken) {
             int slot = taken;
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             if (METHOD == MET2_NNLS) {
                 nnls_solve<NB>(S, bd, st, 0.0, false, lane);
             } else if (METHOD == MET2_T2SPARC) {
-                if (have_seed) { seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane); nnls_solve_warm<NB>(S, bd, st, A.t2sparc_lambda, true, lane); }
+                if (have_seed) { seed_load<NB>(st, A.seed, seed_k, fa, lane); nnls_solve_warm<NB>(S, bd, st, A.t2sparc_lambda, true, lane); }
                 else nnls_solve<NB>(S, bd, st, A.t2sparc_lambda, true, lane);
                 regv = lamv = A.t2sparc_lambda;
             } else if (METHOD == MET2_X2) {
@@ -631,12 +643,11 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 nnls_solve<NB>(S, bd, st, 0.0, false, lane);
                 const double SSE = sse_of<NB>(S, st, b, lane);
                 const double target = A.x2_factor * SSE;
-                int flag, nev = 0;
+                int flag;
                 double last_x = -1.0, last_sse = 0.0;
+                if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);     // start of the first Brent point
                 double lam = fminbound_dev([&](double x) {
-                    if (nev == 0 && have_seed) seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane);
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
-                    ++nev;
                     double SSEr = sse_of<NB>(S, st, b, lane);
                     last_x = x; last_sse = SSEr;
                     return fabs(SSEr - target) / SSE;
@@ -669,11 +680,10 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
                 const double sigma = sqrt(sse_of<NB>(S, st, b, lane) / dof);
                 BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
-                int flag, nev = 0;
+                int flag;
+                if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
-                    if (nev == 0 && have_seed) seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane);
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
-                    ++nev;
                     return bayes_objective<NB>(S, bd, st, bc, x, b, lane);
                 }, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
@@ -682,11 +692,10 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 regv = lamv = lam;
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
-                int flag, overflow = 0, nev = 0;
+                int flag, overflow = 0;
+                if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
-                    if (nev == 0 && have_seed) seed_load<NB>(st, A.seed_x, A.seed_pos, A.seed_ord, seed_k, fa, lane);
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
-                    ++nev;
                     return gcv_objective<NB>(S, bd, st, x, b, lane, overflow);
                 }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
@@ -1312,7 +1321,7 @@ struct met2_plan {
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
     int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;
-    double *dSeedX = nullptr; int *dSeedI = nullptr;      // seed_kernel's output: x [3][nfa][128]; pos | ord [3][nfa][128] each, k [3][nfa]
+    char *dSeed = nullptr;                                // seed_kernel's output: [3][nfa] SeedRec
     bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -1670,8 +1679,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMemset(p->dKd, 0, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
-    HIPCHK(hipMalloc(&p->dSeedX, sizeof(double) * 3 * (size_t)n_fa * 128));
-    HIPCHK(hipMalloc(&p->dSeedI, sizeof(int) * (2 * 3 * (size_t)n_fa * 128 + 3 * (size_t)n_fa)));
+    HIPCHK(hipMalloc(&p->dSeed, sizeof(SeedRec) * 3 * (size_t)n_fa));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1700,7 +1708,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeedX, p->dSeedI};
+    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed};
     for (void *b : bufs) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1949,17 +1957,15 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
     A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
-    A.seed_x = nullptr; A.seed_pos = A.seed_ord = A.seed_k = nullptr;
+    A.seed = nullptr;
     if (!objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
-        const size_t per = (size_t)p->n_fa * 128;
-        int *spos = p->dSeedI, *sord = p->dSeedI + 3 * per, *sk = p->dSeedI + 6 * per;
         if (!p->seeds_valid || p->seeds_t2sparc != p->opt.t2sparc_lambda) {
             SeedArgs SA;
             SA.n = p->n_t2; SA.m = p->n_te; SA.nfa = p->n_fa;
             SA.Dfa = p->dD; SA.Bfa = p->dB; SA.Dtfa = p->dDt; SA.kband = p->dKband; SA.lband = p->dLband; SA.Kd = p->dKd;
             const double gm = 0.5 * (3.0 - sqrt(5.0));
             SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8); SA.lam[2] = p->opt.t2sparc_lambda;
-            SA.x = p->dSeedX; SA.pos = spos; SA.ord = sord; SA.k = sk;
+            SA.out = p->dSeed;
             const int lds = (int)sizeof(double) * col_base(p->n_t2) + 64;
             if (g.nb == 1) {
                 HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1972,7 +1978,7 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
             p->seeds_valid = true; p->seeds_t2sparc = p->opt.t2sparc_lambda;
         }
         const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : 0);
-        A.seed_x = p->dSeedX + slot * per; A.seed_pos = spos + slot * per; A.seed_ord = sord + slot * per; A.seed_k = sk + (size_t)slot * p->n_fa;
+        A.seed = p->dSeed + sizeof(SeedRec) * (size_t)slot * p->n_fa;
     }
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }

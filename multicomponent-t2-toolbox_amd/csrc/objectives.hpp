@@ -130,6 +130,7 @@ __device__ __forceinline__ bool chol_full_rowwise(const WaveShared &S, const Ban
 template <int NB>
 __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
 {
+    lane = lane_opaque(lane);
 #ifdef MET2_CHOL_ROWWISE
     return chol_full_rowwise<NB>(S, bd, beta, lam, lane, det_u);
 #else

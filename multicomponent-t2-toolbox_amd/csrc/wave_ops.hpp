@@ -10,6 +10,12 @@ typedef unsigned long long u64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// The lane number again, but opaque to the optimiser.  Per-lane constants of an inlined routine (column bases, byte offsets,
+// tile coordinates) are loop-invariant in the voxel loop: the compiler hoists them out of it, runs out of registers and spills
+// them (BayesReg at 168 VGPRs: 32 such 64-bit values, reloaded from scratch in the inner loops -- 110 KB of fetches per voxel).
+// Derived from this value they are recomputed in place: a few integer instructions per call.
+__device__ __forceinline__ int lane_opaque(int lane) { asm volatile("" : "+v"(lane)); return lane; }
+
 // broadcast lane `l` (wave-uniform) of v to all lanes (v_readlane_b32 x2 -> SGPR pair)
 __device__ __forceinline__ double bcast(double v, int l)
 {
