@@ -1958,7 +1958,8 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     A.seed = nullptr;
-    if (!objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
+    const bool no_seed = getenv("MET2_NO_SEED") != nullptr;      // test switch: every voxel grows its first passive set from the lambda = 0 solution
+    if (!no_seed && !objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
         if (!p->seeds_valid || p->seeds_t2sparc != p->opt.t2sparc_lambda) {
             SeedArgs SA;
             SA.n = p->n_t2; SA.m = p->n_te; SA.nfa = p->n_fa;

@@ -125,6 +125,50 @@ def test_input_validation_raises_instead_of_reading_out_of_bounds(pkg):
     plan.close()
 
 
+@pytest.mark.parametrize("meth,pen,nte,nt2", [("X2", "L2", 32, 60), ("T2SPARC", "InvT2", 32, 60), ("BayesReg", "I", 32, 60),
+                                              ("GCV", "I", 32, 60), ("X2", "L2", 48, 120)])
+def test_plan_level_seeds_do_not_change_the_minimiser(pkg, monkeypatch, meth, pen, nte, nt2):
+    # The first Brent evaluation (T2SPARC: the single solve) starts from the plan's canonical passive set instead of the voxel's
+    # own lambda = 0 set (met2_hip.hip: seed_kernel).  The regularised problem is strictly convex, so the spectrum at a given
+    # lambda is the same up to rounding; MET2_NO_SEED switches the seeds off at run time.  Brent may flip on ties (the known
+    # rates of DESIGN.md section 2), so the comparison is on voxels whose lambda agrees.
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    alphas = np.linspace(120.0, 180.0, 7)
+    plan = _plan(pkg, alphas, pen=pen, nte=nte, nt2=nt2)
+    n = 6000 if nt2 == 60 else 1500
+    data, fa, _ = synth.make_voxels(n, nte=nte, seed=4242, fa_values=alphas, device="cuda")
+    seeded = plan.fit(meth, data, fa_index=fa, want_lambda=True)
+    again = plan.fit(meth, data, fa_index=fa, want_lambda=True)
+    for k in ("fsol", "sig", "reg", "lam"):
+        assert torch.equal(seeded[k], again[k]), k                   # deterministic, seeds reused
+    monkeypatch.setenv("MET2_NO_SEED", "1")
+    cold = plan.fit(meth, data, fa_index=fa, want_lambda=True)
+    monkeypatch.delenv("MET2_NO_SEED")
+    scale = cold["fsol"].abs().max(dim=1, keepdim=True).values
+    rel = ((seeded["fsol"] - cold["fsol"]).abs() / scale).max(dim=1).values
+    dlam = (seeded["lam"] - cold["lam"]).abs() / cold["lam"].abs().clamp_min(1e-12)
+    same = dlam <= 1e-9                                             # Brent took the same path to the last bit of lambda
+    over = float((rel > TOL).double().mean())
+    print("MEASURED seeds %s/%s %dx%d over 1e-5: %.2e  same-lambda frac=%.4f  max rel fsol there=%.2e  p99 dlam=%.2e" %
+          (meth, pen, nte, nt2, over, float(same.double().mean()), float(rel[same].max()), float(dlam.quantile(0.99))))
+    assert float(rel[same].max()) < 1e-7                            # same lambda -> same spectrum to rounding
+    # voxels beyond 1e-5: Brent flips on ties / flat minima at the rates of DESIGN.md section 2 (GCV: staircase objective)
+    # measured: X2 0 of 6 000 / 1 500, T2SPARC 0, BayesReg/I 5.0e-4, GCV/I 0.165
+    bound = {"X2": 1e-3, "T2SPARC": 0.0, "BayesReg": 2e-3, "GCV": 0.45}[meth]
+    assert over <= bound
+    # a new penalty invalidates the seeds: the refit equals a fresh plan's bits
+    if meth == "X2" and nt2 == 60:
+        T2s = synth.t2_grid(nt2)
+        plan.set_penalty("I", T2s)
+        refit = plan.fit(meth, data, fa_index=fa)
+        fresh = _plan(pkg, alphas, pen="I", nte=nte, nt2=nt2)
+        ref = fresh.fit(meth, data, fa_index=fa)
+        assert torch.equal(refit["fsol"], ref["fsol"]) and torch.equal(refit["reg"], ref["reg"])
+        fresh.close()
+    plan.close()
+
+
 def test_cached_plan_options_are_not_leaked_between_calls(pkg, gS1):
     # nnls_x2(..., factor) / nnls_tik(..., reg_opt) set options on a shared cached plan
     ia = importlib.import_module(PKG + ".intravoxel_algorithms")
