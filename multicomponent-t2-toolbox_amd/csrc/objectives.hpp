@@ -347,7 +347,7 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // different four-dword bank groups (2 np mod 64 is an odd multiple of 4) -- conflict-free.
 __host__ __device__ inline int gcv_row_stride(int m) { int np = m + 4; while ((np & 3) != 2) ++np; return np; }
 __host__ __device__ inline int gcv_vec_len(int m) { return (m + 4 + 1) & ~1; }          // n + 3 entries, padded to even
-__host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = m + 1; return n * gcv_row_stride(m) + 2 * gcv_vec_len(m) + (kcap + 1) / 2 + 2; }
+__host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = m + 1; return n * gcv_row_stride(m) + 3 * gcv_vec_len(m) + (kcap + 1) / 2 + 2; }
 
 // Sturm count: number of eigenvalues < x (<= x up to the measure-zero case of an exactly vanishing minor) of the symmetric
 // tridiagonal matrix given as (d_j, e_{j-1}^2) pairs, by the sign changes of the leading principal minors
@@ -407,6 +407,7 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     double *M = S.R;                         // [n][np], row a of lane a; row/column 0 = the sqrt(c) row of E
     double *vb = M + n * np;                 // [n + 3] Householder vector, zero padded
     double *wb = vb + gcv_vec_len(m);        // [n + 3]
+    double *vb2 = wb + gcv_vec_len(m);       // [n + 3] the Householder vectors alternate between vb and vb2
     // ---- 1. M = A A^T on the matrix cores
     {
         const int li = lane & 15, lk = lane >> 4;
@@ -438,62 +439,101 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
                 }
             }
         if (lane < n) { M[lane * np + n] = 0.0; M[lane * np + n + 1] = 0.0; M[lane * np + n + 2] = 0.0; }
-        if (lane < 3) { vb[n + lane] = 0.0; wb[n + lane] = 0.0; }
+        if (lane < 3) { vb[n + lane] = 0.0; wb[n + lane] = 0.0; vb2[n + lane] = 0.0; }
     }
     __builtin_amdgcn_wave_barrier();
     MET2_GCV_LAP(8);
-    // ---- 2. Householder tridiagonalisation (dsytd2, lower), lane a <-> row a
+    // ---- 2. Householder tridiagonalisation (dsytd2, lower), lane a <-> row a.
+    // One pass over the trailing block per step: the rank-2 update of step j - 1 (M -= v w^T + w v^T) is applied while the
+    // product p = M v of step j is accumulated from the updated values (the arithmetic per element and the order of the sums are
+    // those of two separate passes: same bits).  Column j, which the new reflector is built from, gets the pending update from
+    // registers first.  The steps are a chain of dependent LDS round trips at two waves per SIMD, so a pass less per step is
+    // latency, not bandwidth.
     double dj = 0.0, ej = 0.0;               // lane j: T[j][j], T[j+1][j]
     double *Mrow = M + min(lane, n - 1) * np;
+    double *vprev = vb, *vnext = vb2;        // LDS copies of the pending and of the new reflector (uniform reads of their entries)
+    double vp = 0.0, wp = 0.0;               // this lane's entries of the pending reflector (v, w)
+    bool pend = false;
+    // apply the pending update to columns >= c0 (aligned down to four) without a product
+    auto flush = [&](int c0) {
+        if (lane < n) {
+            for (int b = c0 & ~3; b < n; b += 4) {
+                double m0, m1, m2, m3, u0, u1, u2, u3, q0, q1, q2, q3;
+                lds_quad(Mrow + b, m0, m1, m2, m3);
+                lds_quad(vprev + b, u0, u1, u2, u3);
+                lds_quad(wb + b, q0, q1, q2, q3);
+                met2_d2 *dst = (met2_d2 *)__builtin_assume_aligned(Mrow + b, 16);
+                met2_d2 o0, o1;
+                o0.x = fma(-wp, u0, fma(-vp, q0, m0)); o0.y = fma(-wp, u1, fma(-vp, q1, m1));
+                o1.x = fma(-wp, u2, fma(-vp, q2, m2)); o1.y = fma(-wp, u3, fma(-vp, q3, m3));
+                dst[0] = o0; dst[1] = o1;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     for (int j = 0; j + 2 < n; ++j) {
         const bool below = lane > j && lane < n;
-        const double x = below ? Mrow[j] : 0.0;
-        if (lane == j) dj = Mrow[j];
+        double mj = Mrow[j];
+        if (pend) {                                                   // column j of the matrix the pending update produces
+            const double vj = bcast(vp, j), wj = bcast(wp, j);
+            mj = fma(-wp, vj, fma(-vp, wj, mj));
+        }
+        const double x = below ? mj : 0.0;
+        if (lane == j) dj = mj;
         const double x0 = bcast(x, j + 1);
         const double xn2 = wave_sum((lane > j + 1) ? x * x : 0.0);
-        if (xn2 == 0.0) { if (lane == j) ej = x0; continue; }       // column already in tridiagonal form
+        if (xn2 == 0.0) {                                             // column already in tridiagonal form
+            if (lane == j) ej = x0;
+            if (pend) { flush(j + 1); pend = false; }
+            continue;
+        }
         const double s2 = fma(x0, x0, xn2);
         const double nx = s2 * rsqrt_nr(s2);
         const double alpha = (x0 >= 0.0) ? -nx : nx;
         const double v0 = x0 - alpha;
         const double tau = 2.0 * rcp_nr(fma(v0, v0, xn2));            // H = I - tau v v^T
         const double v = (lane == j + 1) ? v0 : x;                    // zero outside (j, n)
-        // p = tau M v, w = p - (tau/2)(p.v) v, M -= v w^T + w v^T on the trailing block: lane a walks its own row, v and w of
-        // the other rows are uniform-address LDS reads (broadcasting them with v_readlane instead costs six VALU instructions per
-        // matrix element and was measured 1.5x slower)
-        if (lane < n) vb[lane] = v;
+        // p = tau M v, w = p - (tau/2)(p.v) v: lane a walks its own row, v and w of the other rows are uniform-address LDS reads
+        // (broadcasting them with v_readlane instead costs six VALU instructions per matrix element and was measured 1.5x slower)
+        if (lane < n) vnext[lane] = v;
         __builtin_amdgcn_wave_barrier();
         double p = 0.0, p2 = 0.0;
-        const int b0 = (j + 1) & ~3;                                  // 16-byte aligned start: the up to three columns <= j it takes in have v = w = 0
+        const int b0 = (j + 1) & ~3;                                  // 16-byte aligned start: the up to three columns <= j it takes in have v = 0
+        if (pend) {
+            const bool upd = lane >= j && lane < n;                   // rows the pending update (of step j - 1) touches
 #pragma unroll 2
-        for (int b = b0; b < n; b += 4) {                             // may run into the zero padding
-            double m0, m1, m2, m3, u0, u1, u2, u3;
-            lds_quad(Mrow + b, m0, m1, m2, m3);
-            lds_quad(vb + b, u0, u1, u2, u3);
-            p = fma(m0, u0, p); p2 = fma(m1, u1, p2); p = fma(m2, u2, p); p2 = fma(m3, u3, p2);
+            for (int b = b0; b < n; b += 4) {                         // may run into the zero padding
+                double m0, m1, m2, m3, u0, u1, u2, u3, q0, q1, q2, q3, t0, t1, t2, t3;
+                lds_quad(Mrow + b, m0, m1, m2, m3);
+                lds_quad(vprev + b, u0, u1, u2, u3);
+                lds_quad(wb + b, q0, q1, q2, q3);
+                lds_quad(vnext + b, t0, t1, t2, t3);
+                met2_d2 o0, o1;
+                o0.x = fma(-wp, u0, fma(-vp, q0, m0)); o0.y = fma(-wp, u1, fma(-vp, q1, m1));
+                o1.x = fma(-wp, u2, fma(-vp, q2, m2)); o1.y = fma(-wp, u3, fma(-vp, q3, m3));
+                if (upd) { met2_d2 *dst = (met2_d2 *)__builtin_assume_aligned(Mrow + b, 16); dst[0] = o0; dst[1] = o1; }
+                p = fma(o0.x, t0, p); p2 = fma(o0.y, t1, p2); p = fma(o1.x, t2, p); p2 = fma(o1.y, t3, p2);
+            }
+        } else {
+#pragma unroll 2
+            for (int b = b0; b < n; b += 4) {
+                double m0, m1, m2, m3, t0, t1, t2, t3;
+                lds_quad(Mrow + b, m0, m1, m2, m3);
+                lds_quad(vnext + b, t0, t1, t2, t3);
+                p = fma(m0, t0, p); p2 = fma(m1, t1, p2); p = fma(m2, t2, p); p2 = fma(m3, t3, p2);
+            }
         }
         p = below ? tau * (p + p2) : 0.0;
         const double K = 0.5 * tau * wave_sum(p * v);
         const double w = fma(-K, v, p);
-        if (lane < n) wb[lane] = w;
         __builtin_amdgcn_wave_barrier();
-        if (below) {
-#pragma unroll 2
-            for (int b = b0; b < n; b += 4) {
-                double m0, m1, m2, m3, u0, u1, u2, u3, q0, q1, q2, q3;
-                lds_quad(Mrow + b, m0, m1, m2, m3);
-                lds_quad(vb + b, u0, u1, u2, u3);
-                lds_quad(wb + b, q0, q1, q2, q3);
-                met2_d2 *dst = (met2_d2 *)__builtin_assume_aligned(Mrow + b, 16);
-                met2_d2 o0, o1;
-                o0.x = fma(-w, u0, fma(-v, q0, m0)); o0.y = fma(-w, u1, fma(-v, q1, m1));
-                o1.x = fma(-w, u2, fma(-v, q2, m2)); o1.y = fma(-w, u3, fma(-v, q3, m3));
-                dst[0] = o0; dst[1] = o1;
-            }
-        }
+        if (lane < n) wb[lane] = w;                                   // (the pass above was the last reader of the old w)
+        __builtin_amdgcn_wave_barrier();
         if (lane == j) ej = alpha;
-        __builtin_amdgcn_wave_barrier();
+        vp = v; wp = w; pend = true;
+        double *tswap = vprev; vprev = vnext; vnext = tswap;
     }
+    if (pend) flush(n - 2);                                            // the trailing 2 x 2 block still waits for the last update
     if (lane == n - 2) { dj = Mrow[n - 2]; ej = M[(n - 1) * np + n - 2]; }
     if (lane == n - 1) { dj = Mrow[n - 1]; ej = 0.0; }
     // (d_j, e_{j-1}^2) pairs; Gershgorin bound
@@ -570,7 +610,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     if (gcv_lds_doubles(m, k) > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
     // support list (ascending bins) behind the matrices in the wave's LDS region
-    int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 2 * gcv_vec_len(m));
+    int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 3 * gcv_vec_len(m));
     int base = 0;
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
