@@ -693,10 +693,11 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
                 int flag, overflow = 0;
+                GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
-                    return gcv_objective<NB>(S, bd, st, x, b, lane, overflow);
+                    return gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
                 }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
@@ -718,12 +719,13 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                     bc.beta = 1.0 / (sigma * sigma);
                 }
                 double keep = 0.0; int overflow = 0;
+                GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
                 for (int i = 0; i < A.nlam; ++i) {
                     const double x = A.lam_grid[i];
                     nnls_solve<NB>(S, bd, st, x, true, lane);
                     double val;
                     if (BASE == MET2_X2) val = fabs(sse_of<NB>(S, st, b, lane) - A.x2_factor * SSE) / SSE;
-                    else if (BASE == MET2_GCV) val = gcv_objective<NB>(S, bd, st, x, b, lane, overflow);
+                    else if (BASE == MET2_GCV) val = gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
                     else val = bayes_objective<NB>(S, bd, st, bc, x, b, lane);
                     if (lane == i) keep = val;
                 }

@@ -394,9 +394,27 @@ __device__ __forceinline__ void sturm_count3(double dreg, double e2reg, int n, c
     for (int c = 0; c < 3; ++c) out[c] = (int)cnt[c];
 }
 
+// The tridiagonal form of M for a support, at c = 1, kept from one Brent evaluation to the next: M = [[c k, sqrt(c) b^T],
+// [sqrt(c) b, C]] with b = Dr 1 and C = Dr Dr^T.  The first reflector only depends on the direction of b and every later step
+// works on H1 C H1, so c enters T through d_0 = c k and e_0 = sqrt(c) e_0(c = 1) alone.  While the support of the solution does
+// not change (about half of the evaluations of a voxel) the Gram contraction and the tridiagonalisation -- 39 % of the GCV
+// kernel at 48 x 120 -- are skipped and only the bisection and the weights are redone.
+#ifndef MET2_GCV_CACHE
+#define MET2_GCV_CACHE 2
+#endif
 template <int NB>
-__device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, double sc, const int *list, int lane, unsigned long long *cyc = nullptr)
+struct GcvCache {                  // a few entries: Brent's last steps often alternate between neighbouring supports
+    u64 Sm[MET2_GCV_CACHE][NB];            // supports the cached forms belong to
+    double d[MET2_GCV_CACHE], e[MET2_GCV_CACHE]; // lane j: T[j][j], T[j+1][j] at c = 1
+    int valid;         // bit e: entry e holds a form
+    int next;          // entry the next miss overwrites: the one after the entry used last
+};
+
+template <int NB>
+__device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, double c, const int *list, int lane, GcvCache<NB> &tc, bool reuse, int slot,
+                                                   unsigned long long *cyc = nullptr)
 {
+    const double sc = 1.0;                   // the Gram matrix and its tridiagonal form are built at c = 1 (see GcvCache)
 #ifdef MET2_CYCSTATS
     unsigned long long tc0 = __builtin_readcyclecounter();
 #define MET2_GCV_LAP(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (cyc) cyc[slot] += t_ - tc0; tc0 = t_; } while (0)
@@ -408,6 +426,8 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     double *vb = M + n * np;                 // [n + 3] Householder vector, zero padded
     double *wb = vb + gcv_vec_len(m);        // [n + 3]
     double *vb2 = wb + gcv_vec_len(m);       // [n + 3] the Householder vectors alternate between vb and vb2
+    double dj = 0.0, ej = 0.0;               // lane j: T[j][j], T[j+1][j]
+    if (!reuse) {
     // ---- 1. M = A A^T on the matrix cores
     {
         const int li = lane & 15, lk = lane >> 4;
@@ -449,7 +469,6 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     // those of two separate passes: same bits).  Column j, which the new reflector is built from, gets the pending update from
     // registers first.  The steps are a chain of dependent LDS round trips at two waves per SIMD, so a pass less per step is
     // latency, not bandwidth.
-    double dj = 0.0, ej = 0.0;               // lane j: T[j][j], T[j+1][j]
     double *Mrow = M + min(lane, n - 1) * np;
     double *vprev = vb, *vnext = vb2;        // LDS copies of the pending and of the new reflector (uniform reads of their entries)
     double vp = 0.0, wp = 0.0;               // this lane's entries of the pending reflector (v, w)
@@ -536,6 +555,14 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     if (pend) flush(n - 2);                                            // the trailing 2 x 2 block still waits for the last update
     if (lane == n - 2) { dj = Mrow[n - 2]; ej = M[(n - 1) * np + n - 2]; }
     if (lane == n - 1) { dj = Mrow[n - 1]; ej = 0.0; }
+#pragma unroll
+    for (int q = 0; q < MET2_GCV_CACHE; ++q) if (slot == q) { tc.d[q] = dj; tc.e[q] = ej; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < MET2_GCV_CACHE; ++q) if (slot == q) { dj = tc.d[q]; ej = tc.e[q]; }
+        MET2_GCV_LAP(8);
+    }
+    if (lane == 0) { dj = c * (double)k; ej = sqrt(c) * ej; }          // the only entries of T that depend on c
     // (d_j, e_{j-1}^2) pairs; Gershgorin bound
     const double eg = gather(ej, (lane + 63) & 63);                    // cross-lane reads need the full wave: select afterwards
     const double eprev = (lane > 0 && lane < n) ? eg : 0.0;
@@ -586,7 +613,7 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 //   log( (r^2/m) / ((m - trace(Dr G^+ Dr^T))/m)^2 )
 template <int NB>
 __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double x, double b,
-                                                int lane, int &overflow)
+                                                int lane, int &overflow, GcvCache<NB> &tc)
 {
     const int n = S.n, m = S.m;
 #ifdef MET2_CYCSTATS
@@ -609,23 +636,39 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     if (k == 0) return NAN;
     if (gcv_lds_doubles(m, k) > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
+    int slot = -1;
+#pragma unroll
+    for (int q = 0; q < MET2_GCV_CACHE; ++q) {
+        bool hit = ((tc.valid >> q) & 1) != 0;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) hit = hit && (tc.Sm[q][bb] == Sm[bb]);
+        if (hit) slot = q;
+    }
+    const bool reuse = slot >= 0;
+    if (!reuse) slot = tc.next;
+    tc.next = (slot + 1 == MET2_GCV_CACHE) ? 0 : slot + 1;             // two entries: a miss overwrites the one not used last
     // support list (ascending bins) behind the matrices in the wave's LDS region
     int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 3 * gcv_vec_len(m));
-    int base = 0;
+    if (!reuse) {
+        int base = 0;
 #pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-        const int rank = base + __popcll(Sm[bb] & ((1ull << lane) - 1ull));
-        if (inS[bb]) list[rank] = lane + 64 * bb;
-        base += __popcll(Sm[bb]);
+        for (int bb = 0; bb < NB; ++bb) {
+            const int rank = base + __popcll(Sm[bb] & ((1ull << lane) - 1ull));
+            if (inS[bb]) list[rank] = lane + 64 * bb;
+            base += __popcll(Sm[bb]);
+#pragma unroll
+            for (int q = 0; q < MET2_GCV_CACHE; ++q) if (slot == q) tc.Sm[q][bb] = Sm[bb];
+        }
+        tc.valid |= 1 << slot;
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
 #ifdef MET2_CYCSTATS
     const unsigned long long cs0 = __builtin_readcyclecounter();
 #endif
 #ifdef MET2_CYCSTATS
-    const double tr = gcv_trace_direct<NB>(S, k, sqrt(c), list, lane, stw.cyc);
+    const double tr = gcv_trace_direct<NB>(S, k, c, list, lane, tc, reuse, slot, stw.cyc);
 #else
-    const double tr = gcv_trace_direct<NB>(S, k, sqrt(c), list, lane);
+    const double tr = gcv_trace_direct<NB>(S, k, c, list, lane, tc, reuse, slot);
 #endif
 #ifdef MET2_CYCSTATS
     stw.cyc[5] += __builtin_readcyclecounter() - cs0; stw.cyc[6] += 1; stw.cyc[4] += k;
