@@ -455,7 +455,10 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
     if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
                                                                       // one bin per lane: the latency-bound recurrences want waves, the spills of a 128-VGPR build go to HBM
     if (base == MET2_BAYESREG) return (nb == 2) ? 4 : MET2_BAYES_WAVES;  // two bins per lane: the full 120 x 120 factor leaves room for 2 waves per CU
-    return (method <= MET2_LCURVE) ? 16 : 12;
+    // two bins per lane: the factor's LDS footprint (kmax = 72 at nT2 = 120) holds 7 waves per CU anyway, so those kernels are
+    // compiled for 8 (256 VGPRs) instead of spilling at 128 (X2 at 48 x 120: 103 spilled VGPRs)
+    if (method <= MET2_LCURVE) return (nb == 2) ? 8 : 16;
+    return 12;
 }
 
 // Seeds for the first Brent point.  The first abscissa of scipy's bounded Brent is a + 0.382 (b - a) for every voxel, and at

@@ -172,40 +172,88 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
     const int nt = (n + 15) >> 4;
     for (int kb = 0; kb < nt; ++kb) {
         const int r0 = 16 * kb, r1 = min(n, r0 + 16);
-        // (a) the block's rows
-        for (int r = r0; r < r1; ++r) {
-            double a[NB], a2[NB];
+        // (a) the block's rows, two at a time as in refactor(): rows r and r + 1 share the reads of the block's rows above them and
+        //     row r + 1 takes row r's term from registers -- the block is a chain of dependent LDS round trips (one per finished
+        //     row when done singly: 59 % of the BayesReg kernel's wave cycles at 32 x 60), pairs and four-row reads halve their number
+        auto finish = [&](int r, double (&a)[NB], double (&u)[NB]) -> bool {
+            const double d = bcastN<NB>(a, r);
+            const double rinv = rsqrt_nr(d);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { const int c = lane + 64 * b; a[b] = (c >= r && c < n) ? S.R[cbl[b] + r] : 0.0; a2[b] = 0.0; }
-            const double *cr = S.R + col_base(r);                     // column r: U[j][r], j < r
+            for (int b = 0; b < NB; ++b) {
+                const int c = lane + 64 * b;
+                u[b] = a[b] * rinv;                                   // lane r: d * rinv = U[r][r]
+                if (c >= r && c < n) S.R[cbl[b] + r] = u[b];
+                if (c == r) diag[b] = u[b];
+            }
+            return d > 0.0;                                           // scipy raises LinAlgError otherwise
+        };
+        int r = r0;
+        int cbr = col_base(r0);
+        for (; r + 1 < r1; r += 2) {                                  // r is even (r0 is a multiple of 16)
+            double a[NB], c2[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int c = lane + 64 * b;
+                double a0, c0;
+                lds_pair(S.R + cbc[b] + r, a0, c0);                   // rows r, r + 1 of the lane's column
+                a[b] = (c >= r && c < n) ? a0 : 0.0;
+                c2[b] = (c > r && c < n) ? c0 : 0.0;
+            }
+            const double *cr = S.R + cbr, *cr1 = cr + col_len(r);     // columns r and r + 1
             int j = r0;
-            for (; j + 2 <= r; j += 2) {
-                double s0, s1;                                        // j is even and every column starts 16-byte aligned
+#pragma clang loop unroll(disable)
+            for (; j + 4 <= r; j += 4) {
+                double s0, s1, s2, s3, t0, t1, t2, t3;
+                lds_quad(cr + j, s0, s1, s2, s3);
+                lds_quad(cr1 + j, t0, t1, t2, t3);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1, q2, q3;
+                    lds_quad(S.R + cbc[b] + j, q0, q1, q2, q3);
+                    a[b] = fma(-s0, q0, a[b]); c2[b] = fma(-t0, q0, c2[b]);
+                    a[b] = fma(-s1, q1, a[b]); c2[b] = fma(-t1, q1, c2[b]);
+                    a[b] = fma(-s2, q2, a[b]); c2[b] = fma(-t2, q2, c2[b]);
+                    a[b] = fma(-s3, q3, a[b]); c2[b] = fma(-t3, q3, c2[b]);
+                }
+            }
+            if (j < r) {                                              // r - r0 is even: two rows left
+                double s0, s1, t0, t1;
+                lds_pair(cr + j, s0, s1);
+                lds_pair(cr1 + j, t0, t1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1;
+                    lds_pair(S.R + cbc[b] + j, q0, q1);
+                    a[b] = fma(-s0, q0, a[b]); c2[b] = fma(-t0, q0, c2[b]);
+                    a[b] = fma(-s1, q1, a[b]); c2[b] = fma(-t1, q1, c2[b]);
+                }
+            }
+            double u[NB], w[NB];
+            if (!finish(r, a, u)) return false;
+            const double su = bcastN<NB>(u, r + 1);                   // U[r][r+1]
+#pragma unroll
+            for (int b = 0; b < NB; ++b) c2[b] = fma(-su, u[b], c2[b]);
+            if (!finish(r + 1, c2, w)) return false;
+            __builtin_amdgcn_wave_barrier();
+            cbr += col_len(r) + col_len(r + 1);
+        }
+        if (r < r1) {                                                 // odd n: the last row on its own
+            double a[NB], u[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int c = lane + 64 * b; const double a0 = S.R[cbc[b] + r]; a[b] = (c >= r && c < n) ? a0 : 0.0; }
+            const double *cr = S.R + cbr;
+            for (int j = r0; j + 2 <= r; j += 2) {
+                double s0, s1;
                 lds_pair(cr + j, s0, s1);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     double q0, q1;
                     lds_pair(S.R + cbc[b] + j, q0, q1);
-                    a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
+                    a[b] = fma(-s0, q0, a[b]);
+                    a[b] = fma(-s1, q1, a[b]);
                 }
             }
-            if (j < r) {
-                const double s0 = cr[j];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + j], a[b]);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) a[b] += a2[b];
-            const double d = bcastN<NB>(a, r);
-            if (!(d > 0.0)) return false;                             // scipy raises LinAlgError here
-            const double rinv = rsqrt_nr(d);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int c = lane + 64 * b;
-                const double u = a[b] * rinv;                         // lane r: d * rinv = U[r][r]
-                if (c >= r && c < n) S.R[cbl[b] + r] = u;
-                if (c == r) diag[b] = u;
-            }
+            if (!finish(r, a, u)) return false;
             __builtin_amdgcn_wave_barrier();
         }
         // (b) trailing tiles on the matrix cores
