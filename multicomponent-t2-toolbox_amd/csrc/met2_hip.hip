@@ -1385,7 +1385,7 @@ static SortBufs sort_bufs(met2_plan *p)
 struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles, nb, stage; };
 
 // kmax_cap > 0: capacity of the passive set for this launch (fast path); 0: full capacity n.
-static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allow_unstaged = true, int kmax_cap = 0)
+static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allow_unstaged = true, int kmax_cap = 0, int wave_cap = 0)
 {
     const int n = p->n_t2, m = p->n_te;
     g.nb = n > 64 ? 2 : 1;
@@ -1406,7 +1406,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
     const size_t budget = 160 * 1024 - 64;
     if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
     int w = (int)((budget - shared) / per_wave);
-    const int wmax = method_max_waves(method, g.nb);
+    const int wmax = wave_cap > 0 ? wave_cap : method_max_waves(method, g.nb);     // (the FA kernels have their own launch bounds)
     if (w > wmax) w = wmax;
     if (const char *e = getenv("MET2_WAVES")) { int ww = atoi(e); if (ww >= 1 && ww < w) w = ww; }
     g.waves = w; g.block = 64 * w;
@@ -2063,7 +2063,7 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     const int kcap = p->n_te < p->n_t2 ? p->n_te : 0;
     bool fa_stage = false;
     if (const char *e = getenv("MET2_FA_STAGE")) fa_stage = atoi(e) != 0 && p->n_t2 <= 64;
-    int rc = fit_geometry(p, MET2_NNLS, g, !fa_stage, kcap);
+    int rc = fit_geometry(p, MET2_NNLS, g, !fa_stage, kcap, 16);
     if (rc) return rc;
     const int fa_waves = g.waves >= 16 ? 16 : (g.waves >= 8 ? 8 : g.waves);
     if (g.waves != fa_waves) {
