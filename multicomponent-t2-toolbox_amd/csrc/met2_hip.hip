@@ -266,8 +266,10 @@ struct FitArgs {
 
 // SciPy's bounded Brent (scipy.optimize.fminbound, called at algorithms.py:219,280 and
 // bayesian_interpolation.py:101), restated; executed redundantly by all lanes on uniform values.
-template <class F>
-__device__ __forceinline__ double fminbound_dev(F &&fn, double x1, double x2, double xatol, int maxfun, int &flag)
+// on_best() is called whenever the abscissa just evaluated becomes Brent's best point xf (the value fminbound returns): callers
+// keep the solver state of that evaluation and skip the solve scipy's callers repeat at the returned lambda.
+template <class F, class G>
+__device__ __forceinline__ double fminbound_dev(F &&fn, G &&on_best, double x1, double x2, double xatol, int maxfun, int &flag)
 {
     const double sqrt_eps = sqrt(2.2e-16);
     const double golden_mean = 0.5 * (3.0 - sqrt(5.0));
@@ -277,6 +279,7 @@ __device__ __forceinline__ double fminbound_dev(F &&fn, double x1, double x2, do
     double rat = 0.0, e = 0.0;
     double x = xf;
     double fx = fn(x);
+    on_best();
     int num = 1;
     flag = 0;
     double fu = INFINITY;
@@ -320,6 +323,7 @@ __device__ __forceinline__ double fminbound_dev(F &&fn, double x1, double x2, do
             fulc = nfc; ffulc = fnfc;
             nfc = xf; fnfc = fx;
             xf = x; fx = fu;
+            on_best();
         } else {
             if (x < xf) a = x; else b = x;
             if ((fu <= fnfc) || (nfc == xf)) {
@@ -649,16 +653,30 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 int flag;
                 double last_x = -1.0, last_sse = 0.0;
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);     // start of the first Brent point
+                // algorithms.py:220 solves once more at reg_opt.  The solution of the evaluation that made reg_opt Brent's best point is
+                // that solution up to rounding (the solve is deterministic and the minimiser unique): its spectrum, passive set and
+                // SSE are kept as they come by and restored at the end (85 % of the voxels of configs[1] would repeat the solve)
+                double best_x[NB], best_sse = 0.0; int best_pos[NB], best_ord[NB];
                 double lam = fminbound_dev([&](double x) {
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     double SSEr = sse_of<NB>(S, st, b, lane);
                     last_x = x; last_sse = SSEr;
                     return fabs(SSEr - target) / SSE;
+                }, [&]() {
+                    best_sse = last_sse;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
                 }, 0.0, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                // algorithms.py:220 solves once more at reg_opt; when Brent's last evaluation was at reg_opt the
-                // state already holds that solution (the solve is deterministic), so it is not repeated
-                if (lam != last_x) { nnls_solve_warm<NB>(S, bd, st, lam, true, lane); last_sse = sse_of<NB>(S, st, b, lane); }
+                if (lam != last_x) {
+                    int kk = 0;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {
+                        st.x[bb] = best_x[bb]; st.pos[bb] = best_pos[bb]; st.ord[bb] = best_ord[bb];
+                        st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
+                    }
+                    st.k = kk; last_sse = best_sse;
+                }
                 regv = last_sse / SSE;                            // k_est (motor:141-143)
                 lamv = lam;
             } else if (METHOD == MET2_LCURVE) {
@@ -688,7 +706,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double lam = fminbound_dev([&](double x) {
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     return bayes_objective<NB>(S, bd, st, bc, x, b, lane);
-                }, 1e-8, 2.0, A.xtol, A.maxfun, flag);
+                }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
                 nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
@@ -701,7 +719,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double lam = fminbound_dev([&](double x) {
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     return gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
-                }, 1e-8, 10.0, A.xtol, A.maxfun, flag);
+                }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
                 nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
@@ -1171,7 +1189,7 @@ __global__ __launch_bounds__(128) void fa_spline_kernel(SplineArgs A)
         s[i] = t;
     }
     int flag;
-    const double xs = fminbound_dev([&](double x) { return spline_eval_dev(n, sx, y, s, x); }, 90.0, 180.0, 1e-5, 500, flag);
+    const double xs = fminbound_dev([&](double x) { return spline_eval_dev(n, sx, y, s, x); }, []() {}, 90.0, 180.0, 1e-5, 500, flag);
     int best = 0; double dbest = fabs(A.alpha_hr[0] - xs);            // np.argmin(|alpha - x|): first minimum
     for (int a = 1; a < A.nhr; ++a) { double d = fabs(A.alpha_hr[a] - xs); if (d < dbest) { dbest = d; best = a; } }
     A.fa_index[v] = (double)best;
