@@ -681,16 +681,47 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 lamv = lam;
             } else if (METHOD == MET2_LCURVE) {
                 // algorithms.py:88-113
-                double le = 0.0, ln = 0.0;
+                // The solve at the corner (algorithms.py:111) starts from the sweep's state nearest to it: besides the last grid point
+                // the states of four evenly spaced ones are kept (iterate, and position | pivot bin packed in one word): from the last
+                // point alone the passive set had to shrink by up to ~25 bins, one plane-rotation chain each.
+                constexpr int NS = 4;
+                double le = 0.0, ln = 0.0, keep_x[NS][NB];
+                int keep_p[NS][NB];
                 for (int i = 0; i < A.nlam; ++i) {
                     double lam = A.lam_grid[i];
                     nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
                     double sse = sse_of<NB>(S, st, b, lane);
                     double sn = seminorm2<NB>(bd, st.x, n, lane);
                     if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q)
+                        if (i == (q + 1) * A.nlam / (NS + 1) - 1) {
+#pragma unroll
+                            for (int bb = 0; bb < NB; ++bb) { keep_x[q][bb] = st.x[bb]; keep_p[q][bb] = (st.pos[bb] + 1) | (st.ord[bb] << 9); }
+                        }
                 }
                 int corner = select_corner_dev(le, ln, A.nlam, lane);
                 regv = lamv = A.lam_grid[corner];
+                {
+                    int best = -1, dist = A.nlam - 1 - corner;               // the state in hand belongs to the last grid point
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        const int iq = (q + 1) * A.nlam / (NS + 1) - 1;
+                        const int dq = abs(iq - corner);
+                        if (iq >= 0 && dq < dist) { dist = dq; best = q; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q)
+                        if (best == q) {
+                            int kk = 0;
+#pragma unroll
+                            for (int bb = 0; bb < NB; ++bb) {
+                                st.x[bb] = keep_x[q][bb]; st.pos[bb] = (keep_p[q][bb] & 0x1ff) - 1; st.ord[bb] = keep_p[q][bb] >> 9;
+                                st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
+                            }
+                            st.k = kk;
+                        }
+                }
                 nnls_solve_warm<NB>(S, bd, st, regv, true, lane);
             } else if (METHOD == MET2_BAYESREG) {
                 // bayesian_interpolation.py:84-105
