@@ -92,24 +92,35 @@ struct NnlsState {
 };
 
 __device__ __forceinline__ int row_base(int i, int kmax) { return i * kmax - (i * (i - 1)) / 2 - i; } // row-packed factors of objectives.hpp: entry (i,c) at row_base + c
-// the solver's factor: entry (r,c) at col_base(c) + r.  Every column starts on an even index (16 bytes): the sweeps that read
-// four consecutive rows of a column then use two ds_read_b128 (4 LDS cycles each) instead of two ds_read2_b64 (8 each) -- the
-// LDS array was busy 53 % of the X2 kernel's cycles with the unpadded layout (SQ_LDS_IDX_ACTIVE, profiles/r02m_config1_pmc.csv)
-__host__ __device__ __forceinline__ constexpr int col_len(int c) { return (c + 2) & ~1; }                  // entries 0..c, padded to even
-__host__ __device__ __forceinline__ constexpr int col_base(int c) { return ((c * (c + 1)) >> 1) + ((c + 1) >> 1); }   // sum of col_len below c
+// the solver's factor: entry (r,c) at col_base(c) + r, packed by columns without padding.  Lane c owns column c, and the triangular
+// numbers c (c + 1) / 2 are distinct mod 32 for 32 consecutive c: a wave-wide ds_read_b64 / ds_write_b64 of one row of all columns
+// is bank-conflict-free (2 LDS-array cycles per half wave).  Columns padded to 16 bytes for ds_read_b128 (tried first: 162.5 ->
+// 152.9 ms on configs[1]) lose exactly that: SQ_LDS_BANK_CONFLICT rose to 20 % of the LDS cycles of the X2 kernel and 44 % of
+// BayesReg's, modelled 6-13 cycles per b128 instead of 4.  What the padding was for -- four consecutive rows in 8 cycles instead
+// of the 16 of two ds_read2_b64 -- comes from four SINGLE ds_read_b64 (2 cycles each): the loads are volatile (and typed as LDS
+// pointers, so they stay ds_ instructions) so that the compiler does not pair them into ds_read2_b64.
+__host__ __device__ __forceinline__ constexpr int col_len(int c) { return c + 1; }                         // entries 0..c
+__host__ __device__ __forceinline__ constexpr int col_base(int c) { return (c * (c + 1)) >> 1; }           // sum of col_len below c
 
-// four / two consecutive doubles from a 16-byte aligned LDS address (ds_read_b128)
+// four / two consecutive doubles from LDS as single 8-byte reads
 typedef double met2_d2 __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) double *met2_lds_cvp;
 __device__ __forceinline__ void lds_quad(const double *p, double &a, double &b, double &c, double &d)
+{
+    met2_lds_cvp q = (met2_lds_cvp)p;                                  // p points into the wave's LDS region
+    a = q[0]; b = q[1]; c = q[2]; d = q[3];
+}
+__device__ __forceinline__ void lds_pair(const double *p, double &a, double &b)
+{
+    met2_lds_cvp q = (met2_lds_cvp)p;
+    a = q[0]; b = q[1];
+}
+// the same from a 16-byte aligned address (ds_read_b128): rows of GCV's M, whose stride keeps the lanes' 16-byte chunks apart
+__device__ __forceinline__ void lds_quad128(const double *p, double &a, double &b, double &c, double &d)
 {
     const met2_d2 *q = (const met2_d2 *)__builtin_assume_aligned(p, 16);
     const met2_d2 u = q[0], v = q[1];
     a = u.x; b = u.y; c = v.x; d = v.y;
-}
-__device__ __forceinline__ void lds_pair(const double *p, double &a, double &b)
-{
-    const met2_d2 u = *(const met2_d2 *)__builtin_assume_aligned(p, 16);
-    a = u.x; b = u.y;
 }
 
 // ---- NB-aware cross-lane helpers (idx / src index bins or positions 0..64*NB-1) ----

@@ -526,9 +526,9 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
         if (lane < n) {
             for (int b = c0 & ~3; b < n; b += 4) {
                 double m0, m1, m2, m3, u0, u1, u2, u3, q0, q1, q2, q3;
-                lds_quad(Mrow + b, m0, m1, m2, m3);
-                lds_quad(vprev + b, u0, u1, u2, u3);
-                lds_quad(wb + b, q0, q1, q2, q3);
+                lds_quad128(Mrow + b, m0, m1, m2, m3);
+                lds_quad128(vprev + b, u0, u1, u2, u3);
+                lds_quad128(wb + b, q0, q1, q2, q3);
                 met2_d2 *dst = (met2_d2 *)__builtin_assume_aligned(Mrow + b, 16);
                 met2_d2 o0, o1;
                 o0.x = fma(-wp, u0, fma(-vp, q0, m0)); o0.y = fma(-wp, u1, fma(-vp, q1, m1));
@@ -571,10 +571,10 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 #pragma unroll 2
             for (int b = b0; b < n; b += 4) {                         // may run into the zero padding
                 double m0, m1, m2, m3, u0, u1, u2, u3, q0, q1, q2, q3, t0, t1, t2, t3;
-                lds_quad(Mrow + b, m0, m1, m2, m3);
-                lds_quad(vprev + b, u0, u1, u2, u3);
-                lds_quad(wb + b, q0, q1, q2, q3);
-                lds_quad(vnext + b, t0, t1, t2, t3);
+                lds_quad128(Mrow + b, m0, m1, m2, m3);
+                lds_quad128(vprev + b, u0, u1, u2, u3);
+                lds_quad128(wb + b, q0, q1, q2, q3);
+                lds_quad128(vnext + b, t0, t1, t2, t3);
                 met2_d2 o0, o1;
                 o0.x = fma(-wp, u0, fma(-vp, q0, m0)); o0.y = fma(-wp, u1, fma(-vp, q1, m1));
                 o1.x = fma(-wp, u2, fma(-vp, q2, m2)); o1.y = fma(-wp, u3, fma(-vp, q3, m3));
@@ -585,8 +585,8 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 #pragma unroll 2
             for (int b = b0; b < n; b += 4) {
                 double m0, m1, m2, m3, t0, t1, t2, t3;
-                lds_quad(Mrow + b, m0, m1, m2, m3);
-                lds_quad(vnext + b, t0, t1, t2, t3);
+                lds_quad128(Mrow + b, m0, m1, m2, m3);
+                lds_quad128(vnext + b, t0, t1, t2, t3);
                 p = fma(m0, t0, p); p2 = fma(m1, t1, p2); p = fma(m2, t2, p); p2 = fma(m3, t3, p2);
             }
         }
