@@ -5,7 +5,7 @@ Default = configs[1]: synthetic 128x128x64 volume (1 048 576 voxels), nTE=32, nT
 flip angle.  One "step" = one pass of the hot path over one rank's voxels (gates + FA bucketing [+ brute-force FA estimation
 when the config has it] + per-voxel solve + metrics epilogue), inputs and outputs resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W [--config {0,1,2,3,4}] [--scaling {weak,strong}]
+  python bench.py --gpus N --steps K --warmup W [--config {0,1,2,3,4}] [--scaling {weak,strong}] [--gather {maps,all}]
 
   --config   0: 32x32x1 X2/I single FA (the reference's own CPU-runnable case; cpu_baseline also at 1 thread)
              1: 128x128x64 X2/L2 single FA (the metric's config; default)
@@ -13,8 +13,17 @@ when the config has it] + per-voxel solve + metrics epilogue), inputs and output
              4: 200x200x128, nTE=48, nT2=120, GCV/L2, FA brute-force over 91 flip angles
   --scaling  weak   (default): every rank owns a volume of the config's size
              strong: ONE volume of the config's size, its voxel list dealt to the ranks in interleaved 4 096-voxel blocks
-  N>1: launched by torch.distributed.run, one rank per GPU; the step ends with the path's single collective, the gather of the
-  output maps (+ reg_param) on rank 0.
+  --gather   maps (default): the step's single collective moves the six maps + reg_param (56 B/voxel) to rank 0
+             all:  fsol + Est_Signal + reg_param + maps (SURVEY.md section 8e's payload: 792 B/voxel at 32x60)
+
+N > 1: one rank per GPU over RCCL.  Launched by torch.distributed.run (the driver's way) the ranks are already there; started
+plainly (`python bench.py --gpus N`) this process starts them itself -- as a CHILD `python -m torch.distributed.run ...` before
+anything touches the GPU -- relays the child's JSON line and exits with its code.  Fewer than N visible devices is an error, never
+a silent 1-rank run.
+
+Besides `value` (region (i) of SURVEY.md section 8d: device-resident in -> device-resident out) the line carries
+`dict_build_ms` (region (ii): EPG dictionary + Gram matrices + seeds, once per run) and `end_to_end` (region (iii): pinned host
+volume -> chunked H2D -> fit -> D2H of every output on two streams, rank 0's volume).
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +32,8 @@ import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -78,7 +89,7 @@ def cpu_baseline(method, pen, brute, data_cpu, nte, nt2, T2s, T1s, alphas, lam_g
         d = data_cpu[:n]
         t = time.time()
         fa = oracle.fa_bruteforce(D, d, np.ones(n), nthreads=cores)[0] if brute else np.zeros(n)
-        out = oracle.fit_batch(method, D, L, d, fa, np.ones(n), lambda_reg=lam_grid, nthreads=cores)
+        out = oracle.fit_batch(method, D, L, d, fa, np.ones(n), lambda_reg=lam_grid, nthreads=cores, want_lambda=True)
         return time.time() - t, out
 
     n0 = min(max(16 * cores, 16), data_cpu.shape[0])
@@ -88,7 +99,116 @@ def cpu_baseline(method, pen, brute, data_cpu, nte, nt2, T2s, T1s, alphas, lam_g
     dt, out = run(n1)
     return {"value": n1 / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
             "sample": "first %d voxels of the same volume, %s/%s%s, %.1f s, OpenMP over voxels"
-                      % (n1, method, pen, " after brute-force FA" if brute else "", dt)}, (out[0], n1)
+                      % (n1, method, pen, " after brute-force FA" if brute else "", dt)}, (out[0], out[4], n1)
+
+
+def cpu_baseline_scipy(method, pen, data_cpu, nte, nt2, T2s, T1s, alphas, cores, nvox=512):
+    """A second CPU baseline of the REFERENCE's shape: this repo's own SciPy restatement of the reference's per-voxel Python path
+    (scipy.optimize.nnls on the augmented system inside scipy.optimize.fminbound, algorithms.py:211-233) run row by row through
+    joblib worker processes as motor:427-441 does.  The reference's files never travel; this is oracle/scipy_restatement.py,
+    validated against golden_S1 in the CPU suite.  Single-FA X2 configs only (the reference-shaped leg exists to show what the
+    reference's own software stack does per core, not to cover every method)."""
+    from oracle import scipy_restatement as sr
+    from oracle import oracle
+    D = oracle.dictionary_fa_major(nt2, T2s, T1s, nte, 10.0, alphas, 3000.0)[0]
+    L = oracle.penalty(nt2, pen, T2s)
+    n = min(nvox, data_cpu.shape[0])
+    rows = max(cores, 1)
+    t = time.time()
+    sr.fit_rows(method, D, L, data_cpu[:n], n_rows=rows, n_jobs=cores)
+    dt = time.time() - t
+    return {"value": n / dt, "unit": "voxels/s", "cores": cores, "kind": "scipy-restatement",
+            "sample": "first %d voxels of the same volume, %s/%s, %.1f s, scipy.optimize.nnls + fminbound per voxel, joblib "
+                      "(multiprocessing) over %d image rows as motor:435" % (n, method, pen, dt, rows)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torch.distributed.run, BEFORE any GPU call in this
+    process (torch.cuda.device_count() does not initialise the GPU on this image), relay its output and return its exit code."""
+    share = os.environ.get("MET2_BENCH_SHARE_GPU") == "1" or os.environ.get("MET2_BENCH_PLUMBING") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not share:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer ranks than asked\n" % (args.gpus, ndev))
+        return 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def plumbing_main(args, rank, world, mdist):
+    """MET2_BENCH_PLUMBING=1: the N-rank harness (spawn, rendezvous, shard sizes, the packed gather, max-over-ranks timing, the JSON
+    line) WITHOUT any compute -- every rank fills its send buffer with a rank-dependent pattern and rank 0 checks what arrives.
+    For the CPU test of the launcher only; the line says so and carries no throughput."""
+    import torch.distributed as dist
+    nvox = 10007
+    W = 7 if args.gather == "maps" else 99
+    counts = [mdist.shard_count(nvox, r, world) for r in range(world)]
+    maxlen = max(counts)
+    n = counts[rank]
+    send = torch.zeros((maxlen, W), dtype=torch.float64)
+    idx = mdist.shard_indices(nvox, rank, world)
+    send[:n] = idx.to(torch.float64).unsqueeze(1) * 1000.0 + torch.arange(W, dtype=torch.float64).unsqueeze(0)
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.gather(send, bufs, dst=0)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = True
+    if rank == 0 and world > 1:
+        full = torch.empty((nvox, W), dtype=torch.float64)
+        for r in range(world):
+            full[mdist.shard_indices(nvox, r, world)] = bufs[r][: counts[r]]
+        want = torch.arange(nvox, dtype=torch.float64).unsqueeze(1) * 1000.0 + torch.arange(W, dtype=torch.float64).unsqueeze(0)
+        ok = bool(torch.equal(full, want))
+    if rank == 0:
+        print(json.dumps({"metric": "voxels/sec (whole node) at nTE=32, nT2=60; max |MWF-ref|", "value": None, "unit": "voxels/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "none (launcher plumbing test, no compute)",
+                          "config": {"workload": "plumbing test", "ranks_seen": world, "backend": dist.get_backend() if world > 1 else None,
+                                     "gather": args.gather, "gather_bytes_per_voxel": 8 * W, "gather_ok": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 4
+
+
+def end_to_end(plan, pkg, method, data, brute, chunk_vox=131072, reps=2):
+    """Region (iii) of SURVEY.md section 8d on this rank: the volume in PINNED host memory -> chunked H2D -> [FA estimation] -> fit ->
+    D2H of fsol, Est_Signal, reg_param and the six maps into pinned host buffers, copies and kernels overlapped on two streams
+    (motor.fit_host_pipeline, the pipeline recon_met2_arrays uses)."""
+    motor = importlib.import_module(PKG + ".motor")
+    host = torch.empty(data.shape, dtype=torch.float64, pin_memory=True)
+    host.copy_(data)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = motor.fit_host_pipeline(plan, method, host, fa_method="brute-force" if brute else None, chunk=chunk_vox)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    nbytes = host.numel() * 8 + sum(int(t.numel()) * t.element_size() for t in out.values() if torch.is_tensor(t))
+    return {"ms": 1e3 * best, "voxels_per_s": data.shape[0] / best, "chunk_voxels": chunk_vox, "host_bytes_moved": nbytes,
+            "pcie_GBps": nbytes / best / 1e9,
+            "includes": "pinned host volume -> H2D -> %sfit + metrics -> D2H of fsol, Est_Signal, reg_param, maps (two streams, chunks of %d voxels)"
+                        % ("brute-force FA -> " if brute else "", chunk_vox)}
 
 
 def main():
@@ -98,6 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"])
+    ap.add_argument("--gather", type=str, default="maps", choices=["maps", "all"])
     ap.add_argument("--dims", type=str, default="", help="override the config's volume (marks the line as a variant)")
     ap.add_argument("--method", type=str, default="")
     ap.add_argument("--penalty", type=str, default="")
@@ -106,9 +227,17 @@ def main():
     ap.add_argument("--fa", type=str, default="", choices=["", "single", "brute-force"],
                     help="single: constant FA 150 deg; brute-force: per-voxel FA drawn from the 91-grid and estimated on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parity-sample", type=int, default=1 << 17, help="upper bound on the voxels the oracle is run on for the parity block")
     ap.add_argument("--dump-fail", type=str, default="", help="npz path: inputs/outputs of sample voxels whose fsol is >1e-5 off the oracle")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # ---- N > 1 without a torchrun environment: this process only starts the ranks (no GPU call before this point)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     cfg = dict(CONFIGS[args.config])
     variant = False
@@ -120,17 +249,23 @@ def main():
         variant = variant or d != cfg["dims"]
         cfg["dims"] = d
 
+    mdist = importlib.import_module(PKG + ".dist")
+    plumbing = os.environ.get("MET2_BENCH_PLUMBING") == "1"
+    rank, local_rank, world = mdist.init(backend="gloo" if plumbing else None)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if plumbing:
+        sys.exit(plumbing_main(args, rank, world, mdist))
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
-    mdist = importlib.import_module(PKG + ".dist")
-    rank, local_rank, world = mdist.init()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # MET2_BENCH_SHARE_GPU=1 (+ MET2_DIST_BACKEND=gloo) rehearses the N>1 code path on a one-GPU box: every
     # rank uses cuda:0 and the collective runs over gloo on host copies.  Never set for measurements.
-    if os.environ.get("MET2_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("MET2_BENCH_SHARE_GPU") == "1"
+    if share:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("WORLD_SIZE=%d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -141,7 +276,14 @@ def main():
     brute = cfg["fa"] == "brute-force"
     alphas = np.linspace(90.0, 180.0, 91) if brute else np.array([150.0])   # "single FA" = index 60 of the 91-grid
     plan = pkg.Met2Plan(nte, nt2, alphas.shape[0], device=local_rank)
+    # region (ii): dictionary (EPG) + Gram matrices + penalty + plan-level seeds, once per run; timed on the second build
+    # (the first one also pays for loading the code object)
     plan.build_dictionary_epg(T2s, T1s, 10.0, alphas, 3000.0).set_penalty(pen, T2s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.build_dictionary_epg(T2s, T1s, 10.0, alphas, 3000.0).set_penalty(pen, T2s)
+    torch.cuda.synchronize()
+    dict_build_ms = 1e3 * (time.perf_counter() - t0)
     strong = args.scaling == "strong"
     # weak: a volume per rank (its own seed).  strong: the one volume (same seed everywhere), this rank's interleaved blocks of it
     data, _, _ = synth.make_voxels(nvox_total, nte=nte, seed=20260102 + (0 if strong else rank), fa_deg=150.0,
@@ -151,27 +293,36 @@ def main():
         data = data[idx].contiguous()
     nvox = data.shape[0]
     out = {k: torch.empty(s, dtype=torch.float64, device=dev) for k, s in
-           (("fsol", (nvox, nt2)), ("sig", (nvox, nte)), ("reg", (nvox,)), ("maps", (6, nvox)))}
+           (("fsol", (nvox, nt2)), ("sig", (nvox, nte)), ("reg", (nvox,)), ("lam", (nvox,)), ("maps", (6, nvox)))}
     out["status"] = torch.empty((nvox,), dtype=torch.int32, device=dev)
 
     fa_ms = []
     import torch.distributed as dist
-    gloo = world > 1 and dist.get_backend() == "gloo"
+    backend = dist.get_backend() if world > 1 else None
+    gloo = backend == "gloo"
     counts = [mdist.shard_count(nvox_total, r, world) for r in range(world)] if strong else [nvox] * world
     maxlen = max(counts)
+    gather_all = args.gather == "all"
+    W = (nt2 + nte + 1 + 6) if gather_all else 7
     gather_bufs = None
-    send = torch.zeros((maxlen, 7), dtype=torch.float64, device="cpu" if gloo else dev) if world > 1 else None
+    send = torch.zeros((maxlen, W), dtype=torch.float64, device="cpu" if gloo else dev) if world > 1 else None
 
     def step():
         fa_idx = None
         if brute:       # driver step 2 (motor:349-373) on the device, then step 3+4
             fa_idx, _, _ = plan.fa_bruteforce(data)
             fa_ms.append(plan.last_kernel_ms())
-        res = plan.fit(method, data, fa_index=fa_idx, out=out)
-        if world > 1:   # the path's single collective: output maps + reg_param, one packed buffer, to the root over xGMI
+        res = plan.fit(method, data, fa_index=fa_idx, out=out, want_lambda=True)
+        if world > 1:   # the path's single collective: one packed buffer per rank to the root over xGMI
             nonlocal gather_bufs
-            send[:nvox, :6].copy_(res["maps"].t())
-            send[:nvox, 6].copy_(res["reg"])
+            if gather_all:
+                send[:nvox, :nt2].copy_(res["fsol"])
+                send[:nvox, nt2:nt2 + nte].copy_(res["sig"])
+                send[:nvox, nt2 + nte].copy_(res["reg"])
+                send[:nvox, nt2 + nte + 1:].copy_(res["maps"].t())
+            else:
+                send[:nvox, :6].copy_(res["maps"].t())
+                send[:nvox, 6].copy_(res["reg"])
             if rank == 0 and gather_bufs is None:
                 gather_bufs = [torch.empty_like(send) for _ in range(world)]
             dist.gather(send, gather_bufs if rank == 0 else None, dst=0)
@@ -239,8 +390,11 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "voxels_per_gpu": nvox, "fitted_voxels_per_gpu": fitted,
+                       "ranks_seen": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend),
                        "sharding": ("one volume, interleaved 4096-voxel blocks over the ranks" if strong else "one volume per rank") if world > 1 else "single GPU",
-                       "collective": "one gather of [maps | reg_param] (56 B/voxel) to rank 0" if world > 1 else None},
+                       "gather": args.gather, "gather_bytes_per_voxel": 8 * W,
+                       "collective": ("one gather of %s (%d B/voxel) to rank 0" % ("[fsol | Est_Signal | reg_param | maps]" if gather_all else "[maps | reg_param]", 8 * W)) if world > 1 else None},
+            "dict_build_ms": dict_build_ms,
             "roofline": {"bound": "hbm", "kernel": "fit_kernel<%s>" % method, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "bytes_per_voxel": bpv, "counters": pmc_note,
@@ -252,27 +406,42 @@ def main():
             line["roofline"]["fa_kernel_ms"] = float(np.mean(fa_ms[-args.steps:]))
         if not args.no_cpu_baseline:
             cores = host_cores()
-            sample = data[: min(nvox, 1 << 17)].cpu().numpy()
-            cb, (fs_ref, n1) = cpu_baseline(method, pen, brute, sample, nte, nt2, T2s, T1s, alphas, synth.lambda_grid(), cores, seconds=args.cpu_seconds)
+            sample = data[: min(nvox, args.parity_sample)].cpu().numpy()
+            cb, (fs_ref, lam_ref, n1) = cpu_baseline(method, pen, brute, sample, nte, nt2, T2s, T1s, alphas, synth.lambda_grid(), cores, seconds=args.cpu_seconds)
             line["cpu_baseline"] = cb
             if args.config == 0 and cores > 1:      # configs[0] names the reference's 1-core path: the same port on one thread beside it
                 cb1, _ = cpu_baseline(method, pen, brute, sample, nte, nt2, T2s, T1s, alphas, synth.lambda_grid(), 1, seconds=min(args.cpu_seconds, 10.0))
                 line["cpu_baseline_1core"] = cb1
+            if method == "X2" and not brute:
+                try:
+                    line["cpu_baseline_scipy"] = cpu_baseline_scipy(method, pen, sample, nte, nt2, T2s, T1s, alphas, cores)
+                except Exception as e:          # joblib or scipy missing on the box: say so, the port baseline stands
+                    line["cpu_baseline_scipy"] = {"value": None, "kind": "scipy-restatement", "error": repr(e)[:200]}
             got = out["fsol"][:n1].cpu().numpy()
             den = np.max(np.abs(fs_ref), axis=1); den[den == 0] = 1.0
             rel = np.max(np.abs(got - fs_ref), axis=1) / den
             mwf_ref = fs_ref[:, T2s <= 40.0].sum(axis=1) / (fs_ref.sum(axis=1) + 1e-16)
             dm = np.abs(out["maps"][0, :n1].cpu().numpy() - mwf_ref)
-            line["parity"] = {"sample": n1, "against": "oracle (pinned to the reference: tests/test_oracle_golden.py, tests/test_tail_parity.py)",
-                              "max_rel_fsol": float(rel.max()), "frac_over_1e-5": float((rel > 1e-5).mean()),
-                              "max_abs_MWF": float(dm.max()), "median_abs_MWF": float(np.median(dm)), "p99_abs_MWF": float(np.quantile(dm, 0.99))}
+            inside = rel <= 1e-5
+            line["parity"] = {"sample": n1, "against": "oracle (pinned to the reference: tests/test_oracle_golden.py, tests/test_tail_parity.py; the reference "
+                                                        "itself leaves the oracle at 3e-5 of 65 536 voxels, profiles/parity_r03.json)",
+                              "max_rel_fsol": float(rel.max()), "frac_over_1e-5": float((rel > 1e-5).mean()), "n_over_1e-5": int((rel > 1e-5).sum()),
+                              "max_abs_MWF": float(dm.max()), "max_abs_MWF_within_tol": float(dm[inside].max()) if inside.any() else None,
+                              "median_abs_MWF": float(np.median(dm)), "p99_abs_MWF": float(np.quantile(dm, 0.99))}
             if args.dump_fail:
                 bad = np.nonzero(rel > 1e-5)[0]
                 np.savez(args.dump_fail, idx=bad, data=data[:n1].cpu().numpy()[bad], got=got[bad], ref=fs_ref[bad],
-                         reg=out["reg"][:n1].cpu().numpy()[bad])
+                         reg=out["reg"][:n1].cpu().numpy()[bad], lam_hip=out["lam"][:n1].cpu().numpy()[bad], lam_oracle=lam_ref[bad],
+                         n_sample=n1, src_sha=source_sha())
+        if not args.no_end_to_end:
+            try:
+                line["end_to_end"] = end_to_end(plan, pkg, method, data, brute)
+            except Exception as e:
+                line["end_to_end"] = {"error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -9,8 +9,7 @@
 //                           neighbouring entries of the work list read the same D / B rows from L2
 //   fit_kernel<METHOD>      motor:113-162 + motor:443-472: one voxel per wavefront; every wave of the
 //                           persistent workgroups pulls its own voxels from per-XCD queue cursors over
-//                           the FA-sorted list; D, D^T, B and K rows are read through L1/L2 (the
-//                           LDS-staged variant, STAGE = true, is kept behind MET2_STAGE=1)
+//                           the FA-sorted list; D, D^T, B and K rows are read through L1/L2
 //   fa_kernel               fa_estimation.py:74-111: brute force over the plan's flip angles
 //   fa_spline_kernel        fa_estimation.py:54-59
 //   roi_reduce / roi_kernel motor_recon_met2_real_data_ROI.py:405-420: per-ROI mean signal and mean kernel
@@ -144,7 +143,7 @@ struct SortBufs {
     int *bucket_start; // [nfa+1]
     int *chunk_start;  // [nfa+1]
     int *queue;        // [1]
-    int *xq;           // [8]  one queue cursor per XCD (unstaged fit kernel)
+    int *xq;           // [8]  one queue cursor per XCD (fit kernel)
     int *err;          // [1]  bit0: FA index out of range
 };
 
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(256) void requeue_overflow_kernel(int64_t nvox, con
 // fit kernel
 // ------------------------------------------------------------------------------------------
 struct FitArgs {
-    int n, m, nfa, np, kmax, waves, chunk;
+    int n, m, nfa, kmax, waves, chunk;
     int wave_doubles;   // LDS doubles owned by each wave (>= kmax(kmax+1)/2; n*n for GCV)
     int method, nlam, maxfun;
     double x2_factor, t2sparc_lambda, xtol;
@@ -442,8 +441,8 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 }
 
 // METHOD: met2_method, or 10 + method for the objective-grid diagnostic.  NB: T2 bins per lane.
-// STAGE = false (default): D, D^T, B of the voxel's flip angle and K are read through L1/L2; STAGE = true (NB == 1 only,
-// MET2_STAGE=1): D and B of the workgroup's flip angle are copied to LDS and the workgroup shares FA-homogeneous chunks.
+// D, D^T, B of the voxel's flip angle and K are read through L1/L2 (an LDS-staged variant was measured slower in rounds 1
+// and 2 -- it costs three resident waves per CU -- and has been removed).
 // Waves per workgroup the kernel is compiled for: 16 (128 VGPRs) where the method fits that budget without
 // spilling (NNLS, T2SPARC, X2, L-curve), 12 (168 VGPRs) for the two with a second large phase (GCV, BayesReg).
 #ifndef MET2_GCV_WAVES
@@ -461,7 +460,7 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
     if (base == MET2_BAYESREG) return (nb == 2) ? 4 : MET2_BAYES_WAVES;  // two bins per lane: the full 120 x 120 factor leaves room for 2 waves per CU
     // two bins per lane: the factor's LDS footprint (kmax = 72 at nT2 = 120) holds 7 waves per CU anyway, so those kernels are
     // compiled for 8 (256 VGPRs) instead of spilling at 128 (X2 at 48 x 120: 103 spilled VGPRs)
-    if (method <= MET2_LCURVE) return (nb == 2) ? 8 : 16;
+    if (base <= MET2_LCURVE) return (nb == 2) ? 8 : 16;
     return 12;
 }
 
@@ -497,7 +496,7 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
     WaveShared S;
     S.R = smem; S.n = n; S.m = m; S.kmax = n; S.rcap = col_base(n); S.K = A.Kd; S.kband = A.kband;
     S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n; S.DtG = S.Dt;
-    S.bstride = n; S.dstride = n; S.dtstride = m; S.brows_global = true; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.bstride = n; S.dstride = n; S.dtstride = m; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
     Band<NB> bd;
     load_band<NB>(bd, A.kband, A.lband, lane);
     // canonical spectrum on the (log-spaced) T2 axis: 15 % at 13 % of the axis, 85 % at 39 % (20 ms and 80 ms on 10..2000 ms)
@@ -547,56 +546,42 @@ __device__ __forceinline__ void seed_load(NnlsState<NB> &st, const char *seed, i
 
 // SECOND only gives the second pass of the capacity scheme its own kernel symbol (profilers then list the
 // dominant first pass and the small clean-up pass separately); the code is identical.
-template <int METHOD, int NB, bool STAGE, bool SECOND>
+template <int METHOD, int NB, bool SECOND>
 __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(FitArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const int n = A.n, m = A.m, np = A.np, kmax = A.kmax;
+    const int n = A.n, m = A.m, kmax = A.kmax;
     const int tri = A.wave_doubles;
-    double *sB = smem;
-    double *sD = sB + (STAGE ? n * np : 0);
-    double *sR0 = sD + (STAGE ? ((m * np + n * np + 1) & ~1) - n * np : 0);     // the factors start 16-byte aligned
-    double *sR = sR0 + (size_t)wave * tri;
-    int *sI = (int *)(sR0 + (size_t)A.waves * tri);   // [0] chunk id, [1] next voxel slot
+    double *sR = smem + (size_t)wave * tri;             // every wave's region starts 16-byte aligned
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
-    if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
-    else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n;
     Band<NB> bd;
     load_band<NB>(bd, A.kband, A.lband, lane);
     MetricLanes<NB> ml;
     metric_lanes<NB>(ml, A.t2s, n, A.cut_m, A.cut_ie, lane);
 
     const int nchunks = A.sb.chunk_start[A.nfa];
-    int loaded_fa = -1;
     for (int round = 0; round <= nchunks; ++round) {      // the queue hands out each chunk once
-        // unstaged: every WAVE pulls its own (small) chunk from the global queue -- no workgroup barrier anywhere, so a
-        // wave never idles while its neighbours finish their voxels.  Staged: the workgroup shares a chunk (the staged
-        // D and B belong to its flip angle) and hands out its voxels through an LDS counter.
-        int c = 0;
-        if (STAGE) {
-            if (threadIdx.x == 0) { sI[0] = atomicAdd(A.sb.queue, 1); sI[1] = 0; }
-            __syncthreads();
-            c = sI[0];
-        } else {
-            // eight cursors, one per XCD, each over a contiguous eighth of the FA-sorted list: neighbouring voxels are
-            // solved on the same XCD, so their 8-byte outputs (maps, reg, lambda) merge into whole lines in that XCD's L2
-            // before they go to HBM; a wave whose own eighth is used up takes from the next ones
-            c = nchunks;
-            if (lane == 0) {
-                const int xcd = (int)(blockIdx.x & 7u);
-                for (int t = 0; t < 8; ++t) {
-                    const int q = (xcd + t) & 7;
-                    const int qlo = (int)(((int64_t)nchunks * q) >> 3), qhi = (int)(((int64_t)nchunks * (q + 1)) >> 3);
-                    if (qlo >= qhi) continue;
-                    const int i = atomicAdd(A.sb.xq + q, 1);
-                    if (i < qhi - qlo) { c = qlo + i; break; }
-                }
+        // every WAVE pulls its own (small) chunk from the global queue -- no workgroup barrier anywhere, so a wave never
+        // idles while its neighbours finish their voxels.
+        // eight cursors, one per XCD, each over a contiguous eighth of the FA-sorted list: neighbouring voxels are
+        // solved on the same XCD, so their 8-byte outputs (maps, reg, lambda) merge into whole lines in that XCD's L2
+        // before they go to HBM; a wave whose own eighth is used up takes from the next ones
+        int c = nchunks;
+        if (lane == 0) {
+            const int xcd = (int)(blockIdx.x & 7u);
+            for (int t = 0; t < 8; ++t) {
+                const int q = (xcd + t) & 7;
+                const int qlo = (int)(((int64_t)nchunks * q) >> 3), qhi = (int)(((int64_t)nchunks * (q + 1)) >> 3);
+                if (qlo >= qhi) continue;
+                const int i = atomicAdd(A.sb.xq + q, 1);
+                if (i < qhi - qlo) { c = qlo + i; break; }
             }
-            c = __builtin_amdgcn_readfirstlane(c);
         }
+        c = __builtin_amdgcn_readfirstlane(c);
         MET2_STAT(5, round);
         if (c >= nchunks) break;
         int lo = 0, hi = A.nfa;                       // largest fa with chunk_start[fa] <= c
@@ -604,28 +589,12 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
         const int fa = lo;
         const int first = A.sb.bucket_start[fa] + (c - A.sb.chunk_start[fa]) * A.chunk;
         const int cnt = min(A.chunk, A.sb.bucket_start[fa + 1] - first);
-        const double *Bf = A.Bfa + (size_t)fa * n * n;
-        const double *Df = A.Dfa + (size_t)fa * m * n;
-        if (STAGE) {
-            if (fa != loaded_fa) {
-                for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
-                for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
-                loaded_fa = fa;
-                __syncthreads();
-            }
-        } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
-        S.DtG = A.Dtfa + (size_t)fa * m * n;
+        S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
+        S.DtG = S.Dt;
         const int seed_k = (MET2_SEED && A.seed) ? ((const SeedRec *)A.seed)[fa].k : 0;
         const bool have_seed = seed_k > 0 && seed_k <= kmax;
-        for (int taken = 0; taken <= cnt; ++taken) {
-            int slot = taken;
-            if (STAGE) {
-                slot = 0;
-                if (lane == 0) slot = atomicAdd(&sI[1], 1);
-                slot = __builtin_amdgcn_readfirstlane(slot);
-            }
-            MET2_STAT(4, taken);
-            if (slot >= cnt) break;
+        for (int slot = 0; slot < cnt; ++slot) {
+            MET2_STAT(4, slot);
             const int64_t v = A.sb.perm[first + slot];
 
             // ---- load, normalise by the first echo (motor:129-132), h = D^T b
@@ -657,9 +626,30 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 // that solution up to rounding (the solve is deterministic and the minimiser unique): its spectrum, passive set and
                 // SSE are kept as they come by and restored at the end (85 % of the voxels of configs[1] would repeat the solve)
                 double best_x[NB], best_sse = 0.0; int best_pos[NB], best_ord[NB];
+#ifdef MET2_CYCSTATS
+                int evi = 0; double canon = 0.0;
+#endif
                 double lam = fminbound_dev([&](double x) {
+#ifdef MET2_CYCSTATS
+                    unsigned long long snap[8];
+                    for (int q_ = 0; q_ < 8; ++q_) snap[q_] = st.cyc[q_];
+                    const int k0_ = st.k;
+                    const double gm_ = 0.5 * (3.0 - sqrt(5.0));
+                    canon = (evi == 0) ? gm_ * 10.0 : (evi == 1 ? canon + gm_ * (10.0 - canon) : (evi == 2 ? gm_ * 10.0 * (1.0 - gm_) : canon * (1.0 - gm_)));
+                    const bool is_canon = fabs(x - canon) <= 1e-12 * canon;
+#endif
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     double SSEr = sse_of<NB>(S, st, b, lane);
+#ifdef MET2_CYCSTATS
+                    if (lane == 0) {
+                        const int e_ = evi < 39 ? evi : 39;
+                        atomicAdd(&g_ev[e_][0], 1ull);
+                        for (int q_ = 1; q_ < 8; ++q_) atomicAdd(&g_ev[e_][q_], (st.cyc[q_] - snap[q_]) % 1000000000000ull);
+                        atomicAdd(&g_ev[e_][8], (unsigned long long)k0_); atomicAdd(&g_ev[e_][9], (unsigned long long)st.k);
+                        if (is_canon) atomicAdd(&g_ev[e_][10], 1ull);
+                    }
+                    ++evi;
+#endif
                     last_x = x; last_sse = SSEr;
                     return fabs(SSEr - target) / SSE;
                 }, [&]() {
@@ -809,18 +799,16 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 if (A.status) A.status[v] = stat;
             }
         }
-        if (STAGE) __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // brute-force flip-angle estimation (flip_angle_algorithms/fa_estimation.py:74-111):
 // for every flip angle of the dictionary one plain NNLS per voxel, argmin of the residual norm.
-// A workgroup keeps a tile of waves*VPW voxels in registers and walks the FA axis, staging each
-// flip angle's D and B in LDS once per tile.
+// Every wave keeps VPW voxels in registers and walks the FA axis on its own.
 // ------------------------------------------------------------------------------------------
 struct FaArgs {
-    int n, m, nfa, np, kmax, waves, wave_doubles;
+    int n, m, nfa, kmax, waves, wave_doubles;
     const double *Dfa, *Bfa, *Dtfa;
     const double *Kd;         // [n][n], only multiplied by lambda = 0 here (the refactorisation reads its rows)
     const double *data;       // echo e of voxel v at data[v * vs + e * es]
@@ -831,45 +819,31 @@ struct FaArgs {
     int64_t nvox;
 };
 
-template <int VPW, int NB, int WAVES, bool STAGE>
+template <int VPW, int NB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const int n = A.n, m = A.m, np = A.np;
-    double *sB = smem;
-    double *sD = sB + (STAGE ? n * np : 0);
-    double *sR0 = sD + (STAGE ? ((m * np + n * np + 1) & ~1) - n * np : 0);     // the factors start 16-byte aligned
-    double *sR = sR0 + (size_t)wave * A.wave_doubles;
-    int *sI = (int *)(sR0 + (size_t)A.waves * A.wave_doubles);
+    const int n = A.n, m = A.m;
+    double *sR = smem + (size_t)wave * A.wave_doubles;
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.brows_global = !STAGE; S.buffer_rows = false; S.have_bdiag = true; S.bdiag[0] = S.bdiag[1] = 0.0;
-    if (STAGE) { S.B = sB; S.D = sD; S.bstride = np; S.dstride = np; }
-    else { S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n; }
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = false; S.have_bdiag = true; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n;
     Band<NB> bd;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int d = 0; d < 5; ++d) bd.lb[b][d] = 0.0;
-    // staged: a workgroup shares a tile of waves x VPW voxels and the LDS copies of each flip angle's D and B (two
-    // barriers per flip angle).  Unstaged: every wave pulls its own VPW voxels and walks the flip angles alone, reading
-    // D, D^T and B through L1/L2 -- no barrier, so no wave waits for the slowest solve of the tile (the staged kernel
-    // spent 48 % of its wave time in those barriers).
-    const int tile_vox = (STAGE ? A.waves : 1) * VPW;
-    const int64_t ntiles = (A.nvox + tile_vox - 1) / tile_vox;
+    // every wave pulls its own VPW voxels and walks the flip angles alone, reading D, D^T and B through L1/L2 -- no barrier,
+    // so no wave waits for the slowest solve of a tile (a tile kernel with D and B staged in LDS per flip angle spent 48 % of
+    // its wave time in its two barriers per flip angle; removed in round 3).
+    const int64_t ntiles = (A.nvox + VPW - 1) / VPW;
     for (int64_t round = 0; round <= ntiles; ++round) {
-        int64_t tile = 0;
-        if (STAGE) {
-            if (threadIdx.x == 0) sI[0] = atomicAdd(A.queue, 1);
-            __syncthreads();
-            tile = sI[0];
-        } else {
-            int t32 = 0;
-            if (lane == 0) t32 = atomicAdd(A.queue, 1);
-            tile = __builtin_amdgcn_readfirstlane(t32);
-        }
+        int t32 = 0;
+        if (lane == 0) t32 = atomicAdd(A.queue, 1);
+        const int64_t tile = __builtin_amdgcn_readfirstlane(t32);
         if (tile >= ntiles) break;
-        const int64_t v0 = tile * tile_vox + (STAGE ? (int64_t)wave * VPW : 0);
+        const int64_t v0 = tile * VPW;
         double b[VPW], best_r[VPW], best_km[VPW];
         int best_fa[VPW];
         bool act[VPW];
@@ -893,28 +867,13 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
         }
         for (int fa = 0; fa < A.nfa; ++fa) {
             const double *Bf = A.Bfa + (size_t)fa * n * n;
-            const double *Df = A.Dfa + (size_t)fa * m * n;
-            if (STAGE) {
-#ifdef MET2_CYCSTATS
-                const unsigned long long cs0 = __builtin_readcyclecounter();
-#endif
-                __syncthreads();
-#ifdef MET2_CYCSTATS
-                const unsigned long long cs1 = __builtin_readcyclecounter();
-#endif
-                for (int i = threadIdx.x; i < n * n; i += blockDim.x) { int r = i / n, q = i - r * n; sB[r * np + q] = Bf[i]; }
-                for (int i = threadIdx.x; i < m * n; i += blockDim.x) { int r = i / n, q = i - r * n; sD[r * np + q] = Df[i]; }
-                __syncthreads();
-#ifdef MET2_CYCSTATS
-                st[0].cyc[5] += cs1 - cs0; st[0].cyc[6] += __builtin_readcyclecounter() - cs1;
-#endif
-            } else { S.B = Bf; S.D = Df; S.Dt = A.Dtfa + (size_t)fa * m * n; }
+            S.B = Bf; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) { const int j = min(lane + 64 * bb, n - 1); S.bdiag[bb] = Bf[(size_t)j * n + j]; }
 #ifdef MET2_CYCSTATS
             const unsigned long long cv0 = __builtin_readcyclecounter();
 #endif
-            if (!STAGE) {                      // rows of D come from L2: load each once for all the wave's voxels
+            {                                  // rows of D come from L2: load each once for all the wave's voxels
                 double hh[VPW][NB];
                 project_multi<NB, VPW>(S, b, lane, hh);
 #pragma unroll
@@ -925,7 +884,6 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
                 if (!act[vv]) continue;
-                if (STAGE) project<NB>(S, b[vv], lane, st[vv].h);
                 nnls_solve_warm<NB>(S, bd, st[vv], 0.0, false, lane);
                 const double rn = sqrt(sse_of<NB>(S, st[vv], b[vv], lane));
                 if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
@@ -954,7 +912,6 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             }
             if (v < A.nvox && A.resid && !act[vv]) for (int f = lane; f < A.nfa; f += 64) A.resid[(size_t)v * A.nfa + f] = 0.0;
         }
-        if (STAGE) __syncthreads();
     }
 }
 
@@ -1431,46 +1388,53 @@ static SortBufs sort_bufs(met2_plan *p)
     return sb;
 }
 
-struct LaunchGeom { int grid, block, waves, np, kmax, lds, wave_doubles, nb, stage; };
+struct LaunchGeom { int grid, block, waves, kmax, lds, wave_doubles, nb; };
+
+// Development knobs (first-pass capacity, waves per CU, queue granularity) exist only in builds with -DMET2_TUNING; the shipped
+// library reads two environment variables: MET2_NO_SEED (A/B test of the plan-level seeds) and MET2_DEBUG (synchronous progress lines).
+static int tuning_env(const char *name, int lo, int hi, int dflt)
+{
+#ifdef MET2_TUNING
+    if (const char *e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) return v; }
+#else
+    (void)name; (void)lo; (void)hi;
+#endif
+    return dflt;
+}
 
 // kmax_cap > 0: capacity of the passive set for this launch (fast path); 0: full capacity n.
-static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allow_unstaged = true, int kmax_cap = 0, int wave_cap = 0,
-                        int64_t nvox = -1)
+// `method` is the kernel's template method (10 + base for the objective-grid kernels), so that the waves per workgroup come from
+// the same number as the kernel's __launch_bounds__.
+static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, int kmax_cap = 0, int wave_cap = 0, int64_t nvox = -1)
 {
     const int n = p->n_t2, m = p->n_te;
+    const int base = method >= 10 ? method - 10 : method;
     g.nb = n > 64 ? 2 : 1;
-    g.np = n | 1;
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
-    g.wave_doubles = col_base(g.kmax);                                 // the factor, columns padded to 16 bytes (nnls_wave.hpp)
-    if (method == MET2_GCV && gcv_lds_doubles(m, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(m, n);      // M ((m+1)^2) + vectors + support list
+    g.wave_doubles = col_base(g.kmax);                                 // the factor, packed by columns without padding (nnls_wave.hpp)
+    if (base == MET2_GCV && gcv_lds_doubles(m, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(m, n);      // M ((m+1)^2) + vectors + support list
     g.wave_doubles = (g.wave_doubles + 1) & ~1;                        // every wave's region starts 16-byte aligned
-    // stage: D and B of one flip angle copied to LDS next to the per-wave factors; otherwise they are read
-    // through L1/L2 (always for NB == 2, where B alone is 116 KB).  With warm starts a lambda evaluation reads
-    // only ~k rows of B, so the fit kernel prefers the LDS for more resident waves per CU (measured on X2/L2:
-    // staged 8 waves 1.555 M voxels/s, unstaged 8 waves 1.485 M, unstaged 11 waves 1.821 M);
-    // the brute-force FA kernel (cold solves, B-row heavy) stages.
-    g.stage = (g.nb == 1 && !allow_unstaged) ? 1 : 0;
-    if (const char *e = getenv("MET2_STAGE")) if (allow_unstaged) g.stage = (g.nb == 1 && atoi(e) != 0) ? 1 : 0;
-    const size_t shared = g.stage ? sizeof(double) * ((((size_t)n * g.np + (size_t)m * g.np) + 1) & ~(size_t)1) : 0;
+    // D, D^T, B and K are read through L1/L2: with warm starts a lambda evaluation reads only ~k rows of B, and the LDS is worth
+    // more as room for resident waves (measured on X2/L2 in round 1: staged 8 waves 1.555 M voxels/s, unstaged 11 waves 1.821 M)
     const size_t per_wave = sizeof(double) * (size_t)g.wave_doubles;
     const size_t budget = 160 * 1024 - 64;
-    if (shared + per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
-    int w = (int)((budget - shared) / per_wave);
+    if (per_wave > budget) return fail(MET2_E_UNSUPPORTED, "shape does not fit the LDS budget");
+    int w = (int)(budget / per_wave);
     const int wmax = wave_cap > 0 ? wave_cap : method_max_waves(method, g.nb);     // (the FA kernels have their own launch bounds)
     if (w > wmax) w = wmax;
-    // small voxel lists (unstaged: every wave pulls single voxels): no more waves per CU than the list gives every CU, in whole
+    // small voxel lists (every wave pulls single voxels): no more waves per CU than the list gives every CU, in whole
     // multiples of the four SIMDs -- with 16 waves per CU racing for 1 024 voxels the CUs that win run four voxels per SIMD while
     // others idle (configs[0]: 1.16 ms at 16 waves, 0.85 ms at 4)
-    if (nvox >= 0 && !g.stage) {
+    if (nvox >= 0) {
         const int cus = p->cus > 0 ? p->cus : 256;
         int64_t per_cu = (nvox + cus - 1) / cus;
         int ww = (int)(((per_cu + 3) / 4) * 4);
         if (ww < 4) ww = 4;
         if (ww < w) w = ww;
     }
-    if (const char *e = getenv("MET2_WAVES")) { int ww = atoi(e); if (ww >= 1 && ww < w) w = ww; }
+    w = tuning_env("MET2_WAVES", 1, w, w);
     g.waves = w; g.block = 64 * w;
-    g.lds = (int)(shared + per_wave * w + 64);
+    g.lds = (int)(per_wave * w + 64);
     g.grid = p->cus > 0 ? p->cus : 256;
     return MET2_OK;
 }
@@ -1481,7 +1445,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, bool allo
 static int fast_kmax(const met2_plan *p, int method)
 {
     if (method == MET2_BAYESREG || method >= 10) return 0;
-    if (const char *e = getenv("MET2_KMAX")) { int kk = atoi(e); return (kk >= 8 && kk < p->n_t2) ? kk : 0; }
+    { const int kk = tuning_env("MET2_KMAX", 8, p->n_t2 - 1, -1); if (kk > 0) return kk; }
     // the largest capacity that still lets 16 waves share the LDS, but not below 0.6 n
     // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M;
     //  nT2 = 120 with the per-wave queue, where the clean-up pass is cheap: kmax 56 / 64 / 72 / 80 / 96 ->
@@ -1493,11 +1457,12 @@ static int fast_kmax(const met2_plan *p, int method)
     return k < p->n_t2 ? k : 0;
 }
 
-template <int METHOD, int NB, bool STAGE, bool SECOND>
+template <int METHOD, int NB, bool SECOND>
 static int launch_fit_nb(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
 {
-    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB, STAGE, SECOND>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
-    hipLaunchKernelGGL((fit_kernel<METHOD, NB, STAGE, SECOND>), dim3(g.grid), dim3(g.block), g.lds, s, A);
+    if (g.block > 64 * method_max_waves(METHOD, NB)) return fail(MET2_E_INVALID, "launch geometry exceeds the kernel's launch bounds");
+    HIPCHK(hipFuncSetAttribute((const void *)fit_kernel<METHOD, NB, SECOND>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds));
+    hipLaunchKernelGGL((fit_kernel<METHOD, NB, SECOND>), dim3(g.grid), dim3(g.block), g.lds, s, A);
     HIPCHK(hipGetLastError());
     return MET2_OK;
 }
@@ -1507,11 +1472,9 @@ static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s, bool
     if (second) {      // only the capacity-scheme methods have a second pass
         if (METHOD > MET2_LCURVE) return fail(MET2_E_INVALID, "no second pass for this method");
         constexpr int M2 = METHOD > MET2_LCURVE ? MET2_NNLS : METHOD;
-        if (g.nb == 2) return launch_fit_nb<M2, 2, false, true>(A, g, s);
-        return g.stage ? launch_fit_nb<M2, 1, true, true>(A, g, s) : launch_fit_nb<M2, 1, false, true>(A, g, s);
+        return g.nb == 2 ? launch_fit_nb<M2, 2, true>(A, g, s) : launch_fit_nb<M2, 1, true>(A, g, s);
     }
-    if (g.nb == 2) return launch_fit_nb<METHOD, 2, false, false>(A, g, s);
-    return g.stage ? launch_fit_nb<METHOD, 1, true, false>(A, g, s) : launch_fit_nb<METHOD, 1, false, false>(A, g, s);
+    return g.nb == 2 ? launch_fit_nb<METHOD, 2, false>(A, g, s) : launch_fit_nb<METHOD, 1, false>(A, g, s);
 }
 
 // -DMET2_ONLY=<method number> builds the fit kernel of that method only (plus plain NNLS): a development switch that
@@ -1970,9 +1933,9 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     // capacity for the voxels that hit it
     const int kfast = objgrid ? 0 : fast_kmax(p, method);
     LaunchGeom g, g2;
-    rc = fit_geometry(p, method, g, true, kfast, 0, nvox);
+    rc = fit_geometry(p, objgrid ? method + 10 : method, g, kfast, 0, nvox);
     if (rc) return rc;
-    if (kfast) { rc = fit_geometry(p, method, g2, true, 0, 0, nvox); if (rc) return rc; }
+    if (kfast) { rc = fit_geometry(p, method, g2, 0, 0, nvox); if (rc) return rc; }
     if (kfast && !status) {        // the second pass is driven by the status words
         if (p->cap_status < nvox) {
             if (p->dStatus) HIPCHK(hipFree(p->dStatus));
@@ -1990,14 +1953,13 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 16), s));
     const int nb = (int)((nvox + 255) / 256);
-    // work-queue granularity: 128 voxels per workgroup when D/B are staged per flip angle; otherwise every wave pulls
+    // work-queue granularity: every wave pulls
     // its own voxels -- one at a time for the methods that spend ~1 ms per voxel (X2/L2 on configs[1]: 1 / 2 / 4 / 8 / 16
     // voxels per pull -> 5.37 / 5.32 / 5.22 / 5.04 / 4.71 M voxels/s; HBM writes 1.01 / 0.93 / 0.88 / 0.89 GB because the
     // 8-byte per-voxel outputs of neighbouring voxels then leave from different XCDs), eight at a time for NNLS and
     // T2SPARC, where one atomic per voxel on the queue word would cap the kernel at 23 M voxels/s (8 -> 82 M)
-    int chunk = 128;
-    if (!g.stage) chunk = ((objgrid ? method - MET2_OBJECTIVE_GRID : method) <= MET2_T2SPARC) ? 8 : 1;
-    if (const char *e = getenv("MET2_CHUNK")) { int c = atoi(e); if (c >= 1 && c <= 1024) chunk = c; }
+    int chunk = (method <= MET2_T2SPARC) ? 8 : 1;
+    chunk = tuning_env("MET2_CHUNK", 1, 1024, chunk);
     const bool dbg = getenv("MET2_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit: nvox=%lld grid=%d block=%d lds=%d\n", (long long)nvox, g.grid, g.block, g.lds); fflush(stderr); }
     hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, voxel_stride, echo_stride, fa_index, mask, 1, sb, status);
@@ -2013,7 +1975,7 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     }
 
     FitArgs A;
-    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.chunk = chunk; A.wave_doubles = g.wave_doubles;
+    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.kmax = g.kmax; A.waves = g.waves; A.chunk = chunk; A.wave_doubles = g.wave_doubles;
     A.method = method; A.nlam = p->nlam;
     A.maxfun = p->opt.brent_maxfun > 0 ? p->opt.brent_maxfun : (method == MET2_BAYESREG ? 200 : 300);
     A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
@@ -2076,8 +2038,19 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
         HIPCHK(hipMemcpyFromSymbol(cy, HIP_SYMBOL(met2::g_cyc), sizeof(cy)));
         fprintf(stderr, "[met2] gcv trace: gram(mfma)=%llu tridiag=%llu bisect=%llu weights=%llu\n", cy[8], cy[9], cy[10], cy[11]);
         fprintf(stderr, "[met2] calls: warm solves=%llu duals=%llu append rounds=%llu inner loops after an append=%llu\n", cy[12], cy[13], cy[14], cy[15]);
-        fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | slots 5-7 (bayes: chol, upper_times, erf/log; gcv small path: cycles, evaluations, sweeps; append slot += sum k)=%llu %llu %llu\n",
+        fprintf(stderr, "[met2] wave cycles: voxel=%llu refactor=%llu inner=%llu dual=%llu append=%llu | slots 5-7 (x2: sse, removals, removal cycles; bayes: chol, upper_times, erf/log; gcv small path: cycles, evaluations, sweeps; append slot += sum k)=%llu %llu %llu\n",
                 cy[0], cy[1], cy[2], cy[3], cy[4], cy[5], cy[6], cy[7]);
+        if (method == MET2_X2) {
+            static unsigned long long ev[40][12];
+            HIPCHK(hipMemcpyFromSymbol(ev, HIP_SYMBOL(met2::g_ev), sizeof(ev)));
+            fprintf(stderr, "[met2] X2 per Brent evaluation index: evals canonical | cycles per eval: refactor inner(incl. removal) dual append sse | removals/eval removal-cycles/eval | k start -> end\n");
+            for (int e = 0; e < 40; ++e) {
+                if (!ev[e][0]) continue;
+                const double c = (double)ev[e][0];
+                fprintf(stderr, "[met2]  ev %2d: %9llu %9llu | %8.0f %8.0f %8.0f %8.0f %8.0f | %5.2f %8.0f | %5.1f -> %5.1f\n", e, ev[e][0], ev[e][10], ev[e][1] / c, ev[e][2] / c,
+                        ev[e][3] / c, ev[e][4] / c, ev[e][5] / c, ev[e][6] / c, ev[e][7] / c, ev[e][8] / c, ev[e][9] / c);
+            }
+        }
 #endif
 #ifdef MET2_LOOPSTATS
         int ls[8];
@@ -2118,34 +2091,29 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     hipStream_t s = (hipStream_t)stream;
     LaunchGeom g;
     // plain NNLS stops at min(n_t2, n_te) passive bins (Lawson-Hanson's k >= rows test), so the factor needs that
-    // capacity only: 4 KB per wave at nTE = 32 instead of 14.6 KB.  Default: unstaged (every wave walks the flip angles
-    // on its own, 16 waves per CU); MET2_FA_STAGE=1 selects the tile kernel with D and B staged in LDS (nT2 <= 64).
+    // capacity only: 4 KB per wave at nTE = 32 instead of 14.6 KB; every wave walks the flip angles on its own, 16 waves per CU.
     const int kcap = p->n_te < p->n_t2 ? p->n_te : 0;
-    bool fa_stage = false;
-    if (const char *e = getenv("MET2_FA_STAGE")) fa_stage = atoi(e) != 0 && p->n_t2 <= 64;
-    int rc = fit_geometry(p, MET2_NNLS, g, !fa_stage, kcap, 16);
+    int rc = fit_geometry(p, MET2_NNLS, g, kcap, 16);
     if (rc) return rc;
     const int fa_waves = g.waves >= 16 ? 16 : (g.waves >= 8 ? 8 : g.waves);
     if (g.waves != fa_waves) {
         g.waves = fa_waves; g.block = 64 * fa_waves;
-        g.lds = (int)(sizeof(double) * ((((size_t)p->n_t2 * g.np + (size_t)p->n_te * g.np) + 1) & ~(size_t)1) * (g.stage ? 1 : 0) + sizeof(double) * (size_t)g.wave_doubles * fa_waves + 64);
+        g.lds = (int)(sizeof(double) * (size_t)g.wave_doubles * fa_waves + 64);
     }
     SortBufs sb = sort_bufs(p);
     HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
-    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.np = g.np; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
+    A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
     A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Kd = p->dKd; A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
     HIPCHK(hipEventRecord(p->ev0, s));
-#define MET2_FA_LAUNCH(VPW, NB, WAVES, STG)                                                                              \
+#define MET2_FA_LAUNCH(VPW, NB, WAVES)                                                                                   \
     do {                                                                                                                \
-        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
-        hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES, STG>), dim3(g.grid), dim3(g.block), g.lds, s, A);                  \
+        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
+        hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES>), dim3(g.grid), dim3(g.block), g.lds, s, A);                       \
     } while (0)
-    if (g.nb == 1) {
-        if (g.stage) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16, true); else MET2_FA_LAUNCH(4, 1, 8, true); }
-        else         { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16, false); else MET2_FA_LAUNCH(4, 1, 8, false); }
-    } else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16, false); else MET2_FA_LAUNCH(2, 2, 8, false); }   // two voxels per wave at two bins per lane: same 57 ms (measured)
+    if (g.nb == 1) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16); else MET2_FA_LAUNCH(4, 1, 8); }
+    else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16); else MET2_FA_LAUNCH(2, 2, 8); }   // two voxels per wave at two bins per lane: same 57 ms (measured)
 #undef MET2_FA_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev1, s));
@@ -2243,7 +2211,7 @@ int met2_plan_launch_info(met2_plan *p, int32_t method, int32_t *grid, int32_t *
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
     LaunchGeom g;
     const int kf = fast_kmax(p, method);
-    int rc = fit_geometry(p, method, g, true, kf);
+    int rc = fit_geometry(p, method, g, kf);
     if (rc) return rc;
     if (grid) *grid = g.grid;
     if (block) *block = g.block;

@@ -19,9 +19,7 @@
 // doubles.  A lane's walk down its own column is then a run of consecutive addresses (ds_read2 with immediate
 // offsets in the refactorisation and the substitutions) and lanes of neighbouring columns never share a bank
 // (triangular numbers are distinct mod 32).
-// B (n x n) and D (m x n) are read through S.B / S.D: LDS copies of the workgroup's flip angle
-// when they fit (NB = 1; odd row stride -> conflict-free rows and columns), global memory (L2)
-// otherwise.
+// B (n x n), K, D (m x n) and D^T of the voxel's flip angle are read from global memory through L1/L2 (S.B, S.K, S.D, S.Dt).
 #pragma once
 #include "wave_ops.hpp"
 
@@ -36,6 +34,9 @@ __device__ int g_loopstats[8];
 
 #ifdef MET2_CYCSTATS
 __device__ unsigned long long g_cyc[16];
+// per Brent-evaluation index (X2 kernel): [0] evaluations, [1] refactor, [2] inner, [3] dual, [4] append, [5] sse cycles, [6] removals,
+// [7] removal cycles, [8] sum of k at the start, [9] sum of k at the end, [10] evaluations on the canonical (voxel-independent) abscissa
+__device__ unsigned long long g_ev[40][12];
 #define MET2_CYC_BEGIN(var) const unsigned long long var = __builtin_readcyclecounter()
 #define MET2_CYC_END(slot, var) st.cyc[slot] += __builtin_readcyclecounter() - var
 #define MET2_CYC_ADD(slot, v) st.cyc[slot] += (unsigned long long)(v)
@@ -52,15 +53,14 @@ __device__ unsigned long long g_cyc[16];
 struct WaveShared {
     const double *B;    // [n][bstride]
     const double *K;    // [n][n] dense L^T L in global memory (fit kernel only)
-    const double *Dt;   // [n][dtstride] transposed D in global memory, or NULL (then columns of D are read)
-    const double *DtG;  // the same array, always set (the GCV Gram contraction gathers its operands from it in every kernel variant)
+    const double *Dt;   // [n][dtstride] transposed D in global memory
+    const double *DtG;  // the same array (the GCV Gram contraction gathers its operands from it)
     const double *kband; // [5][128] diagonals of K in global memory: kband[d*128 + j] = K[j][j+d-2] (loaded where the stencil is applied)
     int dtstride;
     const double *D;    // [m][dstride]
     double *R;          // this wave's LDS region
     int n, m, bstride, dstride, kmax;
     int rcap;           // doubles available at R
-    bool brows_global;  // B and D point to global memory (false: the LDS copies of the staged kernel variants)
     bool have_bdiag;    // bdiag holds B[j][j] of the lane's bins (the FA walk sets it once per flip angle: its refactorisations are too
     double bdiag[2];    // short -- k ~ 8 -- to hide the latency of loading the diagonal inside refactor())
     bool buffer_rows;   // row loads of the global matrices as raw buffer loads (fit kernels); false: plain global loads (the FA walk, whose
@@ -304,6 +304,7 @@ template <int NB>
 __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &st, int p, int lane)
 {
     const int k = st.k;
+    MET2_CYC_BEGIN(c_rm);
     const int tb = bcastN_i<NB>(st.ord, p);
     if (p < k - 1) {
         int cbl[NB];                                                    // col_base of the lane's own (old) column
@@ -370,6 +371,8 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
     }
     clear_bit<NB>(st.P, tb);
     st.k = k - 1;
+    MET2_CYC_END(7, c_rm);
+    MET2_CYC_ADD(6, 1);
 }
 
 // Try to move bin t from Z to P.  Returns false (state untouched) when the column is numerically
@@ -385,7 +388,7 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
     for (int b = 0; b < NB; ++b) {
         const int j = lane + 64 * b;
         const unsigned je = (unsigned)min(j, S.n - 1);
-        const double bv = ld_row_sel(S.brows_global && S.buffer_rows, S.B, t * S.bstride, je);
+        const double bv = ld_row_sel(S.buffer_rows, S.B, t * S.bstride, je);
         gb[b] = (j < S.n) ? bv : 0.0;
         if (lam != 0.0) gb[b] = fma(lam, (j < S.n) ? ld_row_sel(S.buffer_rows, S.K, t * S.n, je) : 0.0, gb[b]);       // G[j][t] (K is symmetric: row t)
     }
@@ -488,7 +491,7 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
             const int pp = p + q;                                        // <= 64 NB - 1 (p <= k - 1 <= 64 NB - 1 is a multiple of 4)
             const int trow = bcastN_i<NB>(st.ord, pp) * S.bstride;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) v[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, trow, jc[b]);
+            for (int b = 0; b < NB; ++b) v[q][b] = ld_row_sel(S.buffer_rows, S.B, trow, jc[b]);
             xs[q] = bcastN<NB>(xp, pp);
         }
 #pragma unroll
@@ -677,7 +680,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
         const int t = bcastN_i<NB>(st.ord, min(p, k - 1));
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            vb[b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, t * S.bstride, jc[b]);
+            vb[b] = ld_row_sel(S.buffer_rows, S.B, t * S.bstride, jc[b]);
             vk[b] = ld_row_sel(S.buffer_rows, S.K, t * n, jc[b]);
         }
     };
@@ -730,7 +733,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
         int j = 0;
 #pragma clang loop unroll(disable)
         for (; j + 4 <= i; j += 4) {                                    // four rows above per step: the three LDS pointers are bumped once per eight FMAs
-            double s0, s1, s2, s3, u0, u1, u2, u3;                      // j is a multiple of 4 and every column starts 16-byte aligned
+            double s0, s1, s2, s3, u0, u1, u2, u3;                      // columns are NOT 16-byte aligned: lds_quad must stay four single 8-byte reads
             lds_quad(ci + j, s0, s1, s2, s3);
             lds_quad(cj + j, u0, u1, u2, u3);
 #pragma unroll
@@ -876,7 +879,7 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
             const int t = bcastN_i<NB>(st.ord, i + q);                  // i + q <= 64 NB - 1 (i is a multiple of 4 below k <= 64 NB)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                vb[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, t * S.bstride, jc[b]);
+                vb[q][b] = ld_row_sel(S.buffer_rows, S.B, t * S.bstride, jc[b]);
                 vk[q][b] = (lam != 0.0) ? ld_row_sel(S.buffer_rows, S.K, t * n, jc[b]) : 0.0;
             }
         }
@@ -931,7 +934,7 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
             int j = r0;
 #pragma clang loop unroll(disable)
             for (; j + 4 <= i; j += 4) {
-                double s0, s1, s2, s3, u0, u1, u2, u3;                  // j is a multiple of 4 and every column starts 16-byte aligned
+                double s0, s1, s2, s3, u0, u1, u2, u3;                  // columns are NOT 16-byte aligned: lds_quad must stay four single 8-byte reads
                 lds_quad(ci + j, s0, s1, s2, s3);
                 lds_quad(cj + j, u0, u1, u2, u3);
 #pragma unroll
@@ -1097,34 +1100,24 @@ template <int NB>
 __device__ __forceinline__ double model_signal(const WaveShared &S, const NnlsState<NB> &st, int lane)
 {
     const int k = st.k;
-    if (S.Dt) {
-        // rows of D^T: coalesced, four in flight per step
-        double acc = 0.0, acc2 = 0.0, xp[NB];
+    // rows of D^T: coalesced, four in flight per step
+    double acc = 0.0, acc2 = 0.0, xp[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { const double t = gatherN<NB>(st.x, st.ord[b]); xp[b] = (lane + 64 * b < k) ? t : 0.0; }   // as in dual()
-        const unsigned ec = (unsigned)min(lane, S.m - 1);
+    for (int b = 0; b < NB; ++b) { const double t = gatherN<NB>(st.x, st.ord[b]); xp[b] = (lane + 64 * b < k) ? t : 0.0; }   // as in dual()
+    const unsigned ec = (unsigned)min(lane, S.m - 1);
 #pragma clang loop unroll(disable)
-        for (int p = 0; p < k; p += 4) {
-            double v[4], xs[4];
+    for (int p = 0; p < k; p += 4) {
+        double v[4], xs[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pp = p + q;
-                v[q] = ld_row_sel(S.buffer_rows, S.Dt, bcastN_i<NB>(st.ord, pp) * S.dtstride, ec);
-                xs[q] = bcastN<NB>(xp, pp);
-            }
-            acc = fma(v[0], xs[0], acc); acc2 = fma(v[1], xs[1], acc2);
-            acc = fma(v[2], xs[2], acc); acc2 = fma(v[3], xs[3], acc2);
+        for (int q = 0; q < 4; ++q) {
+            const int pp = p + q;
+            v[q] = ld_row_sel(S.buffer_rows, S.Dt, bcastN_i<NB>(st.ord, pp) * S.dtstride, ec);
+            xs[q] = bcastN<NB>(xp, pp);
         }
-        return acc + acc2;
+        acc = fma(v[0], xs[0], acc); acc2 = fma(v[1], xs[1], acc2);
+        acc = fma(v[2], xs[2], acc); acc2 = fma(v[3], xs[3], acc2);
     }
-    double acc = 0.0;
-    for (int p = 0; p < k; ++p) {
-        int i = bcastN_i<NB>(st.ord, p);
-        double xi = bcastN<NB>(st.x, i);
-        double dv = (lane < S.m) ? S.D[lane * S.dstride + i] : 0.0;
-        acc = fma(dv, xi, acc);
-    }
-    return acc;
+    return acc + acc2;
 }
 
 // || D x - b ||^2

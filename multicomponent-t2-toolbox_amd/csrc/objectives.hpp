@@ -16,112 +16,10 @@ __device__ __forceinline__ double wave_prod(double v)
     return (bcast(v, 0) * bcast(v, 16)) * (bcast(v, 32) * bcast(v, 48));
 }
 
-// Upper Cholesky factor U (A = U^T U) of A = beta*B + (beta*lam)*K, packed by columns into S.R like the solver's
-// factor (entry (r, c) at col_base(c) + r; needs kmax == n).  Row by row as in refactor(): a lane owns columns
-// lane + 64 b, row j costs j independent LDS reads + FMAs in batches of four, the rows of B and of the dense K for
-// the next pivot are in flight meanwhile.  Returns false when a pivot is not positive (scipy raises LinAlgError there).
-template <int NB>
-__device__ __forceinline__ bool chol_full_rowwise(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
-{
-    const int n = S.n;
-    const double bl = beta * lam;
-    int cbl[NB], cbc[NB];
-    unsigned jc[NB];
-    double diag[NB], gb0[NB], gk0[NB], gb1[NB], gk1[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int pl = lane + 64 * b;
-        cbl[b] = col_base(pl);
-        cbc[b] = col_base(min(pl, n - 1));
-        jc[b] = (unsigned)min(pl, n - 1);
-        diag[b] = 1.0;
-    }
-    auto fetch = [&](int j, double (&vb)[NB], double (&vk)[NB]) {
-        const int jj = min(j, n - 1);
-        const double *Brow = S.B + jj * S.bstride, *Krow = S.K + jj * n;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { vb[b] = Brow[jc[b]]; vk[b] = Krow[jc[b]]; }
-    };
-    // scale a finished row, store its column entries; false when the pivot is not positive
-    auto finish = [&](int j, double (&a)[NB], double (&u)[NB]) -> bool {
-        const double d = bcastN<NB>(a, j);
-        const double rinv = rsqrt_nr(d);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int c = lane + 64 * b;
-            u[b] = a[b] * rinv;                                         // lane j: d * rinv = U[j][j]
-            if (c >= j && c < n) S.R[cbl[b] + j] = u[b];
-            if (c == j) diag[b] = u[b];
-        }
-        return d > 0.0;
-    };
-    fetch(0, gb0, gk0);
-    fetch(1, gb1, gk1);
-    int cbj = 0;                                                        // col_base(j)
-    int j = 0;
-    for (; j + 1 < n; j += 2) {                                         // rows j and j + 1 together, as in refactor()
-        double a[NB], a2[NB], c[NB], c2[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            a[b] = fma(bl, gk0[b], beta * gb0[b]); c[b] = fma(bl, gk1[b], beta * gb1[b]);                     // A[j][.], A[j+1][.]
-            a2[b] = 0.0; c2[b] = 0.0;
-        }
-        fetch(j + 2, gb0, gk0);
-        fetch(j + 3, gb1, gk1);
-        const double *cj = S.R + cbj, *cj1 = cj + col_len(j);           // columns j and j + 1
-        int k = 0;
-#pragma clang loop unroll(disable)
-        for (; k + 2 <= j; k += 2) {
-            const double s0 = cj[k], s1 = cj[k + 1];
-            const double u0 = cj1[k], u1 = cj1[k + 1];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const double *cc = S.R + cbc[b] + k;
-                const double q0 = cc[0], q1 = cc[1];
-                a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
-                c[b] = fma(-u0, q0, c[b]); c2[b] = fma(-u1, q1, c2[b]);
-            }
-        }
-        for (; k < j; ++k) {
-            const double s0 = cj[k], u0 = cj1[k];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { const double q0 = S.R[cbc[b] + k]; a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]); }
-        }
-        double u[NB], w[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) { a[b] += a2[b]; c[b] += c2[b]; }
-        if (!finish(j, a, u)) return false;
-        const double su = bcastN<NB>(u, j + 1);                         // U[j][j+1]
-#pragma unroll
-        for (int b = 0; b < NB; ++b) c[b] = fma(-su, u[b], c[b]);
-        if (!finish(j + 1, c, w)) return false;
-        __builtin_amdgcn_wave_barrier();
-        cbj += col_len(j) + col_len(j + 1);
-    }
-    if (j < n) {                                                        // odd n: the last row on its own
-        double a[NB], u[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) a[b] = fma(bl, gk0[b], beta * gb0[b]);
-        const double *cj = S.R + cbj;
-        for (int k = 0; k < j; ++k) {
-            const double s0 = cj[k];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + k], a[b]);
-        }
-        if (!finish(j, a, u)) return false;
-        __builtin_amdgcn_wave_barrier();
-    }
-    double dp = 1.0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) dp *= (lane + 64 * b < n) ? diag[b] : 1.0;
-    det_u = wave_prod(dp);
-    return true;
-}
-
-
-// The same factor by a blocked right-looking Cholesky with the trailing update on the matrix cores (the default; the row-wise
-// routine above stays behind -DMET2_CHOL_ROWWISE for A/B runs).  A = beta B + beta lam K is first written into the wave's
-// LDS region (upper triangle, packed by columns like U).  Then, per block row of 16:
+// Upper Cholesky factor U (A = U^T U) of A = beta*B + (beta*lam)*K, packed by columns into S.R like the solver's factor
+// (entry (r, c) at col_base(c) + r; needs kmax == n), by a blocked right-looking Cholesky with the trailing update on the
+// matrix cores (the row-wise routine of round 1 measured 11 % slower on configs[3] and has been removed).  A = beta B +
+// beta lam K is first written into the wave's LDS region (upper triangle, packed by columns like U).  Then, per block row of 16:
 //   (a) its rows are finished row by row, lane <-> column, with the inner products restricted to the rows of the block
 //       (<= 15 terms instead of up to n - 1: everything above the block has already been subtracted by the trailing updates);
 //   (b) every trailing 16 x 16 tile C(ti, tj), ti <= tj, takes C -= U(block, ti)^T U(block, tj) as four v_mfma_f64_16x16x4
@@ -131,9 +29,6 @@ template <int NB>
 __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &bd, double beta, double lam, int lane, double &det_u)
 {
     lane = lane_opaque(lane);
-#ifdef MET2_CHOL_ROWWISE
-    return chol_full_rowwise<NB>(S, bd, beta, lam, lane, det_u);
-#else
     const int n = S.n;
     const double bl = beta * lam;
     int cbl[NB], cbc[NB];
@@ -155,7 +50,7 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
             const int jj = min(j + q, n - 1);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                vb[q][b] = ld_row_sel(S.brows_global && S.buffer_rows, S.B, jj * S.bstride, jc[b]);
+                vb[q][b] = ld_row_sel(S.buffer_rows, S.B, jj * S.bstride, jc[b]);
                 vk[q][b] = ld_row_sel(S.buffer_rows, S.K, jj * n, jc[b]);
             }
         }
@@ -299,7 +194,6 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
     for (int b = 0; b < NB; ++b) dp *= (lane + 64 * b < n) ? diag[b] : 1.0;
     det_u = wave_prod(dp);
     return true;
-#endif
 }
 
 // (U f)_i for the factor in S.R; the owner of row i gets row i . f

@@ -612,6 +612,74 @@ def gen_tail(tag, nte, npc, nvox, methods, seed, procs=7, chunk=32):
     print("wrote golden_tail_%s.npz (%d arrays)" % (tag, len(out)))
 
 
+def _x2_worker(args):
+    """nnls_x2 of the reference on one chunk of voxels (forked worker)."""
+    lo, hi = args
+    import intravoxel_algorithms.algorithms as alg
+    D, M, L = _TAIL["D"], _TAIL["M"], _TAIL["L"]
+    n = hi - lo
+    f = np.zeros((n, D.shape[1])); lam = np.zeros(n); kest = np.zeros(n)
+    for i in range(n):
+        with np.errstate(all="ignore"):
+            f[i], lam[i], kest[i] = alg.nnls_x2(D, M[lo + i], L, 1.02)
+    return lo, f, lam, kest
+
+
+def _x2_reference(D, M, L, procs=7, chunk=64, tag=""):
+    import multiprocessing as mp
+    _TAIL.update(D=D, M=M, L=L)
+    nvox = M.shape[0]
+    F = np.zeros((nvox, D.shape[1])); Lm = np.zeros(nvox); Ke = np.zeros(nvox)
+    jobs = [(lo, min(nvox, lo + chunk)) for lo in range(0, nvox, chunk)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        for k, (lo, f, lam, kest) in enumerate(pool.imap_unordered(_x2_worker, jobs)):
+            F[lo:lo + f.shape[0]] = f; Lm[lo:lo + f.shape[0]] = lam; Ke[lo:lo + f.shape[0]] = kest
+            if k % 64 == 0:
+                print("  %s: chunk %d / %d" % (tag, k + 1, len(jobs)), flush=True)
+    return F, Lm, Ke
+
+
+def gen_tail_x2(nvox, seed, procs=7):
+    """configs[1]'s method (X2/L2, 32 x 60, FA 150) on enough voxels through the reference's nnls_x2 (algorithms.py:211-233) that
+    a 6e-5 tail is countable.  To keep the file small the signals are rounded to float32 BEFORE they go through the reference
+    (so the stored float32 array IS the input, exactly) and the reference's spectra are stored as float32 (relative rounding
+    6e-8, far inside the 1e-5 tolerance); lambda, k_est and the MWF of the float64 spectra stay float64."""
+    from epg.epg import create_Dic_3D, epg_signal
+    from motor.motor_recon_met2_real_data import create_Laplacian_matrix
+    nte, npc = 32, 60
+    rng = np.random.default_rng(seed)
+    T2s = t2_grid(npc); T1s = 1000.0 * np.ones_like(T2s)
+    D = np.ascontiguousarray(create_Dic_3D(npc, T2s, T1s, nte, 10.0, np.array([150.0]), 3000.0)[:, :, 0])
+    data, _ = synth_voxels(rng, nvox, nte, epg_signal, fa_deg=150.0)
+    data = data.astype(np.float32).astype(np.float64)
+    M = data / data[:, :1]
+    L = penalties(npc, T2s, create_Laplacian_matrix)["L2"]
+    F, Lm, Ke = _x2_reference(D, M, L, procs=procs, tag="tail X2/L2")
+    mwf = F[:, T2s <= 40.0].sum(axis=1) / (F.sum(axis=1) + 1e-16)
+    np.savez_compressed(os.path.join(HERE, "golden_tail_X2.npz"), T2s=T2s, T1s=T1s, TR=3000.0, tau=10.0, nte=nte, npc=npc, D150=D,
+                        data=data.astype(np.float32), X2_L2_f=F.astype(np.float32), X2_L2_lam=Lm, X2_L2_aux=Ke, X2_L2_mwf=mwf)
+    print("wrote golden_tail_X2.npz (%d voxels)" % nvox)
+
+
+def gen_x2_failset(path):
+    """The voxels of configs[1] where the HIP path and the oracle differ by more than 1e-5 (bench.py --dump-fail on the GPU box),
+    through the reference's own nnls_x2: which of the two, if either, does the reference side with?"""
+    from motor.motor_recon_met2_real_data import create_Laplacian_matrix
+    from epg.epg import create_Dic_3D
+    z = np.load(path)
+    nte, npc = z["data"].shape[1], z["got"].shape[1]
+    T2s = t2_grid(npc); T1s = 1000.0 * np.ones_like(T2s)
+    D = np.ascontiguousarray(create_Dic_3D(npc, T2s, T1s, nte, 10.0, np.array([150.0]), 3000.0)[:, :, 0])
+    L = penalties(npc, T2s, create_Laplacian_matrix)["L2"]
+    data = z["data"]
+    M = data / data[:, :1]
+    F, Lm, Ke = _x2_reference(D, M, L, procs=min(7, max(1, data.shape[0])), chunk=4, tag="X2 fail set")
+    out = {k: z[k] for k in z.files}
+    out.update(T2s=T2s, D150=D, ref_f=F * data[:, :1], ref_lam=Lm, ref_kest=Ke)
+    np.savez_compressed(os.path.join(HERE, "golden_x2_failset.npz"), **out)
+    print("wrote golden_x2_failset.npz (%d voxels)" % data.shape[0])
+
+
 def main():
     install_shims()
     which = sys.argv[1:] or ["S1", "S2", "motor", "nesma", "smooth", "roi"]
@@ -632,6 +700,10 @@ def main():
     if "tailS1" in which:
         gen_tail("S1", 32, 60, 4096, [("NNLS", "I", 4096), ("X2", "L2", 4096), ("X2", "I", 1024), ("L_curve", "L1", 4096),
                                       ("BayesReg", "InvT2", 4096), ("BayesReg", "I", 1024), ("GCV", "L2", 4096)], 20260121)
+    if "tailX2" in which:        # ~8 minutes on 7 processes
+        gen_tail_x2(65536, 20260123)
+    if "x2fail" in which:        # needs gpurun_out/fail_x2l2.npz (bench.py --config 1 --dump-fail on the GPU box)
+        gen_x2_failset(os.environ.get("MET2_FAILSET", os.path.join(HERE, "..", "..", "gpurun_out", "fail_x2l2.npz")))
     if "tailS2" in which:
         gen_tail("S2", 48, 120, 512, [("X2", "L2", 512), ("L_curve", "L1", 512), ("BayesReg", "InvT2", 512), ("GCV", "L2", 512)],
                  20260122)
