@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MET2_ABI_VERSION 2
+#define MET2_ABI_VERSION 3
 
 /* reg_method of motor/motor_recon_met2_real_data.py:134-150 */
 enum met2_method {
@@ -106,7 +106,10 @@ int met2_plan_get_dictionary(met2_plan *plan, double *dic3d_host);
 
 /* motor:86 create_Laplacian_matrix / motor:263 InvT2.  T2s (host, [n_t2]) is needed for
  * InvT2 only.  The dense form takes any `Laplac` [n_t2][n_t2] (host) whose L^T L has
- * bandwidth <= 2 (true for I, L1, L2, InvT2); wider ones return MET2_E_UNSUPPORTED. */
+ * bandwidth <= 2 (true for I, L1, L2, InvT2); wider ones return MET2_E_UNSUPPORTED.
+ * The plan-level seeds of the lambda searches are (re)built here and wherever the dictionary changes (these entries block);
+ * they are used only if D^T D + lambda L^T L is positive definite (checked for flip angle 0) -- with a penalty whose null
+ * space meets the dictionary's the minimiser is not unique and every voxel starts cold, as the reference does. */
 int met2_plan_set_penalty(met2_plan *plan, int32_t which, const double *T2s);
 int met2_plan_set_penalty_dense(met2_plan *plan, const double *laplac_host);
 int met2_plan_get_penalty(met2_plan *plan, double *laplac_host);
@@ -146,6 +149,17 @@ int met2_fit(met2_plan *plan, int32_t method, int64_t nvox, const double *data, 
 int met2_fit_strided(met2_plan *plan, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
                      int64_t echo_stride, const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg,
                      double *lam, double *maps, int32_t *status, void *stream);
+
+/* The same without waiting for the GPU: the launches are enqueued on `stream` and the call returns (the blocking entries above
+ * wait only to report an FA index outside the dictionary, the reference's IndexError at motor:127-128).  A host pipeline --
+ * H2D of the next chunk of a volume, this fit, D2H of the previous chunk's outputs, on separate streams (motor:167-182,
+ * :427-503 are that loop in the reference, one image row at a time) -- enqueues chunk after chunk and calls met2_plan_finish
+ * once: it waits for `stream` and returns MET2_E_INVALID if any fit enqueued since the last finish saw such an index.
+ * One plan serves one stream at a time (its sort scratch is per plan). */
+int met2_fit_enqueue_strided(met2_plan *plan, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
+                             int64_t echo_stride, const double *fa_index, const uint8_t *mask, double *fsol, double *sig,
+                             double *reg, double *lam, double *maps, int32_t *status, void *stream);
+int met2_plan_finish(met2_plan *plan, void *stream);
 
 /* Test/diagnostic entry: `method` = 10 + MET2_X2 / MET2_GCV / MET2_BAYESREG passed to met2_fit
  * evaluates that method's lambda-selection objective (algorithms.py:226-233, :285-296,

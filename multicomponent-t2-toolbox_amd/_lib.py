@@ -24,7 +24,7 @@ class Options(C.Structure):
 SYMBOLS = ["met2_default_options", "met2_abi_version", "met2_device_count", "met2_last_error", "met2_plan_create",
            "met2_plan_destroy", "met2_plan_set_options", "met2_plan_get_options", "met2_plan_build_dictionary_epg", "met2_plan_set_dictionary", "met2_plan_get_dictionary",
            "met2_plan_set_penalty", "met2_plan_set_penalty_dense", "met2_plan_get_penalty", "met2_plan_set_lambda_grid",
-           "met2_plan_set_t2_grid", "met2_fit", "met2_fit_strided", "met2_fa_bruteforce", "met2_fa_bruteforce_strided", "met2_fa_spline_select",
+           "met2_plan_set_t2_grid", "met2_fit", "met2_fit_strided", "met2_fit_enqueue_strided", "met2_plan_finish", "met2_fa_bruteforce", "met2_fa_bruteforce_strided", "met2_fa_spline_select",
            "met2_fa_spline_select_strided", "met2_roi_reduce", "met2_nesma", "met2_smooth_separable", "met2_metrics", "met2_plan_last_kernel_ms", "met2_plan_last_second_pass_ms",
            "met2_plan_launch_info"]
 
@@ -52,6 +52,8 @@ def lib():
         L.met2_plan_set_t2_grid.argtypes = [vp, _dp]
         L.met2_fit.argtypes = [vp, C.c_int32, C.c_int64] + [vp] * 10
         L.met2_fit_strided.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, C.c_int64] + [vp] * 9
+        L.met2_fit_enqueue_strided.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, C.c_int64] + [vp] * 9
+        L.met2_plan_finish.argtypes = [vp, vp]
         L.met2_fa_bruteforce.argtypes = [vp, C.c_int64] + [vp] * 6
         L.met2_fa_bruteforce_strided.argtypes = [vp, C.c_int64, vp, C.c_int64, C.c_int64] + [vp] * 5
         L.met2_fa_spline_select_strided.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, vp, C.c_int32, _dp, C.c_int32, vp, C.c_int64, C.c_int64,

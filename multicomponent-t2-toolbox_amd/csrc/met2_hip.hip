@@ -1334,6 +1334,10 @@ struct met2_plan {
     int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;
     char *dSeed = nullptr;                                // seed_kernel's output: [3][nfa] SeedRec
     bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
+    bool seeds_ok = false;                                // B + lambda K is positive definite at the seed lambdas (checked on the host for
+                                                          // flip angle 0): only then is the seeded start the cold start's solution
+    int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
+    bool err_pending = false;
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool timed = false, timed2 = false;
@@ -1655,6 +1659,70 @@ extern "C" int met2_fa_spline_select(int32_t device, int64_t nvox, int32_t n_lr,
     return met2_fa_spline_select_strided(device, nvox, n_lr, alpha_lr, resid, n_hr, alpha_hr, n_te, data, n_te, 1, mask, fa_index, xmin, stream);
 }
 
+
+// Plan-level seeds (seed_kernel) are built where the dictionary, the penalty or T2SPARC's lambda are SET -- entries that
+// synchronise -- never inside a fit: a fit on another stream or thread only ever reads finished records.
+// Seeded starts equal the cold-start solution only when B + lambda K is positive definite (one minimiser).  That holds for the
+// reference's I / L1 / L2 / InvT2; met2_plan_set_penalty_dense takes any banded L, e.g. a pure second difference whose null
+// space meets that of D.  Checked here on the host by a Cholesky factorisation of B_0 + lambda K (flip angle 0, the three seed
+// lambdas) with a relative pivot threshold; when it fails the plan simply runs unseeded.
+static bool host_posdef(int n, std::vector<double> G)
+{
+    double dmax = 0.0;
+    for (int i = 0; i < n; ++i) dmax = std::max(dmax, fabs(G[(size_t)i * n + i]));
+    for (int j = 0; j < n; ++j) {
+        double d = G[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= G[(size_t)j * n + k] * G[(size_t)j * n + k];
+        if (!(d > 1e-13 * dmax)) return false;
+        d = sqrt(d);
+        G[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double t = G[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) t -= G[(size_t)i * n + k] * G[(size_t)j * n + k];
+            G[(size_t)i * n + j] = t / d;
+        }
+    }
+    return true;
+}
+
+static int ensure_seeds(met2_plan *p, hipStream_t s)
+{
+    if (!p->have_dict || !p->have_pen) return MET2_OK;
+    if (p->seeds_valid && p->seeds_t2sparc == p->opt.t2sparc_lambda) return MET2_OK;
+    const int n = p->n_t2;
+    const double gm = 0.5 * (3.0 - sqrt(5.0));
+    SeedArgs SA;
+    SA.n = n; SA.m = p->n_te; SA.nfa = p->n_fa;
+    SA.Dfa = p->dD; SA.Bfa = p->dB; SA.Dtfa = p->dDt; SA.kband = p->dKband; SA.lband = p->dLband; SA.Kd = p->dKd;
+    SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8); SA.lam[2] = p->opt.t2sparc_lambda;
+    SA.out = p->dSeed;
+    {
+        std::vector<double> B0((size_t)n * n), K((size_t)n * n);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpy(B0.data(), p->dB, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(K.data(), p->dKd, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (int q = 0; q < 3 && ok; ++q) {
+            std::vector<double> G((size_t)n * n);
+            for (size_t i = 0; i < G.size(); ++i) G[i] = B0[i] + SA.lam[q] * K[i];
+            ok = SA.lam[q] > 0.0 && host_posdef(n, G);
+        }
+        p->seeds_ok = ok;
+    }
+    const int lds = (int)sizeof(double) * col_base(n) + 64;
+    if (n <= 64) {
+        HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    p->seeds_valid = true; p->seeds_t2sparc = p->opt.t2sparc_lambda;
+    return MET2_OK;
+}
+
 extern "C" {
 
 void met2_default_options(met2_options *o)
@@ -1694,7 +1762,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     if (opt) { memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size); }
     else met2_default_options(&p->opt);
     if (p->opt.device < 0 || p->opt.device >= ndev) { delete p; return fail(MET2_E_INVALID, "device ordinal out of range"); }
-    USE_DEVICE(p->opt.device);
+    DevGuard dev_guard_(p->opt.device);
+    if (dev_guard_.err != hipSuccess) { delete p; return fail(MET2_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(dev_guard_.err)); }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, p->opt.device));
     p->cus = prop.multiProcessorCount;
@@ -1708,6 +1777,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
     HIPCHK(hipMalloc(&p->dSeed, sizeof(SeedRec) * 3 * (size_t)n_fa));
+    HIPCHK(hipHostMalloc((void **)&p->hErr, sizeof(int), hipHostMallocDefault));
+    *p->hErr = 0;
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1722,7 +1793,8 @@ int met2_plan_set_options(met2_plan *p, const met2_options *opt)
     if (!p || !opt) return fail(MET2_E_INVALID, "NULL argument");
     if (opt->device != p->opt.device) return fail(MET2_E_INVALID, "a plan cannot change device");
     memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size);
-    return MET2_OK;
+    USE_DEVICE(p->opt.device);
+    return ensure_seeds(p, 0);       // T2SPARC's seed belongs to its lambda
 }
 
 int met2_plan_get_options(met2_plan *p, met2_options *opt)
@@ -1738,6 +1810,7 @@ int met2_plan_destroy(met2_plan *p)
     DevGuard dev_guard_(p->opt.device);
     void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed};
     for (void *b : bufs) (void)hipFree(b);
+    if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->ev2) (void)hipEventDestroy(p->ev2);
@@ -1785,6 +1858,8 @@ int met2_plan_build_dictionary_epg(met2_plan *p, const double *T2s, const double
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(tmp));
     if (rc) return rc;
+    rc = ensure_seeds(p, s);
+    if (rc) return rc;
     return met2_plan_set_t2_grid(p, T2s);
 }
 
@@ -1801,7 +1876,8 @@ int met2_plan_set_dictionary(met2_plan *p, const double *dic)
     int rc = build_gram(p, 0);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipFree(tmp));
-    return rc;
+    if (rc) return rc;
+    return ensure_seeds(p, 0);
 }
 
 int met2_plan_get_dictionary(met2_plan *p, double *dic)
@@ -1848,7 +1924,7 @@ int met2_plan_set_penalty_dense(met2_plan *p, const double *L)
     p->Lhost.assign(L, L + (size_t)n * n);
     p->log_detL = log(det_lu(n, L));
     p->have_pen = true; p->seeds_valid = false;
-    return MET2_OK;
+    return ensure_seeds(p, 0);
 }
 
 int met2_plan_set_penalty(met2_plan *p, int32_t which, const double *T2s)
@@ -1908,9 +1984,41 @@ int met2_fit(met2_plan *p, int32_t method, int64_t nvox, const double *data, con
     return met2_fit_strided(p, method, nvox, data, p->n_te, 1, fa_index, mask, fsol, sig, reg, lam, maps, status, stream);
 }
 
+static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                    const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
+                    int32_t *status, void *stream, bool sync);
+
 int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
                      const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
                      int32_t *status, void *stream)
+{
+    return fit_impl(p, method, nvox, data, voxel_stride, echo_stride, fa_index, mask, fsol, sig, reg, lam, maps, status, stream, true);
+}
+
+int met2_fit_enqueue_strided(met2_plan *p, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                             const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
+                             int32_t *status, void *stream)
+{
+    return fit_impl(p, method, nvox, data, voxel_stride, echo_stride, fa_index, mask, fsol, sig, reg, lam, maps, status, stream, false);
+}
+
+int met2_plan_finish(met2_plan *p, void *stream)
+{
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    USE_DEVICE(p->opt.device);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (p->err_pending) {
+        p->err_pending = false;
+        const int herr = *p->hErr;
+        *p->hErr = 0;
+        if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
+    }
+    return MET2_OK;
+}
+
+static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride, int64_t echo_stride,
+                    const double *fa_index, const uint8_t *mask, double *fsol, double *sig, double *reg, double *lam, double *maps,
+                    int32_t *status, void *stream, bool sync)
 {
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
     if (voxel_stride == 0 || echo_stride == 0) return fail(MET2_E_INVALID, "zero stride");
@@ -1951,7 +2059,11 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
     }
     if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 128, s));
     SortBufs sb = sort_bufs(p);
-    HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 16), s));
+    {   // counters and cursors start at zero; the error word (index 4 (nfa + 1) + 1) keeps what earlier ENQUEUED fits may have set
+        const size_t e = 4 * (size_t)(p->n_fa + 1) + 1;
+        HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (p->err_pending ? e : e + 1), s));
+        HIPCHK(hipMemsetAsync(p->dSmall + e + 1, 0, sizeof(int) * 14, s));
+    }
     const int nb = (int)((nvox + 255) / 256);
     // work-queue granularity: every wave pulls
     // its own voxels -- one at a time for the methods that spend ~1 ms per voxel (X2/L2 on configs[1]: 1 / 2 / 4 / 8 / 16
@@ -1986,26 +2098,9 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
 
     A.seed = nullptr;
     const bool no_seed = getenv("MET2_NO_SEED") != nullptr;      // test switch: every voxel grows its first passive set from the lambda = 0 solution
-    if (!no_seed && !objgrid && p->have_pen && (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
-        if (!p->seeds_valid || p->seeds_t2sparc != p->opt.t2sparc_lambda) {
-            SeedArgs SA;
-            SA.n = p->n_t2; SA.m = p->n_te; SA.nfa = p->n_fa;
-            SA.Dfa = p->dD; SA.Bfa = p->dB; SA.Dtfa = p->dDt; SA.kband = p->dKband; SA.lband = p->dLband; SA.Kd = p->dKd;
-            const double gm = 0.5 * (3.0 - sqrt(5.0));
-            SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8); SA.lam[2] = p->opt.t2sparc_lambda;
-            SA.out = p->dSeed;
-            const int lds = (int)sizeof(double) * col_base(p->n_t2) + 64;
-            if (g.nb == 1) {
-                HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
-            } else {
-                HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
-            }
-            HIPCHK(hipGetLastError());
-            p->seeds_valid = true; p->seeds_t2sparc = p->opt.t2sparc_lambda;
-        }
-        const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : 0);
+    if (!no_seed && !objgrid && p->have_pen && p->seeds_valid && p->seeds_ok && p->seeds_t2sparc == p->opt.t2sparc_lambda &&
+        (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
+        const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : 0);      // records built by ensure_seeds() when the plan was configured
         A.seed = p->dSeed + sizeof(SeedRec) * (size_t)slot * p->n_fa;
     }
     HIPCHK(hipEventRecord(p->ev0, s));
@@ -2064,12 +2159,12 @@ int met2_fit_strided(met2_plan *p, int32_t method, int64_t nvox, const double *d
                            objgrid ? nullptr : sig, reg, objgrid ? nullptr : lam, objgrid ? nullptr : maps);
         HIPCHK(hipGetLastError());
     }
-    // FA index range errors are reported synchronously (they would be IndexError in the reference)
-    int herr = 0;
-    HIPCHK(hipMemcpyAsync(&herr, sb.err, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
-    return MET2_OK;
+    // FA index range errors (IndexError in the reference): the error word lands in the plan's pinned host word; the blocking entries
+    // wait for it here, an enqueued fit leaves it to met2_plan_finish (errors of several enqueued fits accumulate: the kernel ORs)
+    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    p->err_pending = true;
+    if (!sync) return MET2_OK;
+    return met2_plan_finish(p, stream);
 }
 
 int met2_fa_bruteforce(met2_plan *p, int64_t nvox, const double *data, const uint8_t *mask, double *fa_index, double *km,
@@ -2158,6 +2253,8 @@ int met2_roi_reduce(met2_plan *src, met2_plan *dst, int64_t nvox, const double *
     HIPCHK(hipMemcpyAsync(&herr, A.err, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(scratch));
+    if (rc) return rc;
+    rc = ensure_seeds(dst, s);
     if (rc) return rc;
     if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
     return MET2_OK;

@@ -18,10 +18,11 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+def init(backend=None, single=False):
+    """Initialise the default process group from the torchrun environment.  World size 1 needs no group and gets none, unless
+    `single` asks for one (a one-rank RCCL group: the communicator and the gather below then really run, on one GPU)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -104,7 +105,7 @@ def fit_sharded(fit_fn, nvox, root=0, gather=("maps", "reg"), block=BLOCK, devic
     out = fit_fn(idx)
     n = int(idx.numel())
     buf, widths = _pack(out, gather, n)
-    if world == 1:
+    if not dist.is_initialized():
         full = buf
         order = idx
     else:

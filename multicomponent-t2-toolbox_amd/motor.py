@@ -107,6 +107,110 @@ def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
     return out.cpu().numpy() if as_numpy else out
 
 
+def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=131072, want_lambda=False):
+    """Driver steps 2-4 (motor:349-373, 427-472) for a voxel list that lives in HOST memory, as the reference's driver holds it
+    (motor:167-182): chunks of `chunk` voxels go H2D on one stream, through [brute-force FA estimation and] the fit on a second,
+    and the outputs D2H on a third, double-buffered, so that the copies of chunks c+1 and c-1 run under the fit of chunk c.  The
+    fits are only enqueued (met2_fit_enqueue_strided); one met2_plan_finish at the end waits and reports.
+      host_data [nvox, n_te] float64: a pinned torch CPU tensor is copied from in place; pageable memory (numpy arrays, ordinary
+                tensors) is staged through two pinned chunk buffers
+      fa_method None (fa_index given, or flip angle 0 for all) | 'brute-force' (estimated per chunk on the device)
+      fa_index, mask: host arrays [nvox] or None
+    Returns pinned CPU tensors: fsol [nvox, n_t2], sig [nvox, n_te], reg [nvox], maps [6, nvox], status [nvox] (int32), fa_index
+    [nvox] and lam when asked; chunking changes nothing in them (every voxel is solved on its own)."""
+    dev = plan.device
+    src = host_data if torch.is_tensor(host_data) else torch.from_numpy(np.ascontiguousarray(host_data, dtype=np.float64))
+    if src.is_cuda or src.dtype != torch.float64 or src.dim() != 2 or src.shape[1] != plan.n_te or not src.is_contiguous():
+        raise ValueError("host_data must be a contiguous float64 [nvox, n_te=%d] array in host memory" % plan.n_te)
+    nvox, nte, nt2 = int(src.shape[0]), plan.n_te, plan.n_t2
+    chunk = max(1, min(int(chunk), max(nvox, 1)))
+    nch = (nvox + chunk - 1) // chunk
+    pin = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True)
+    res = {"fsol": pin((nvox, nt2)), "sig": pin((nvox, nte)), "reg": pin((nvox,)), "maps": pin((6, nvox)), "status": pin((nvox,), torch.int32),
+           "fa_index": pin((nvox,))}
+    if want_lambda:
+        res["lam"] = pin((nvox,))
+    if nvox == 0:
+        return res
+    fa_h = None if fa_index is None else torch.from_numpy(np.ascontiguousarray(np.asarray(fa_index, dtype=np.float64).reshape(-1)))
+    mk_h = None if mask is None else torch.from_numpy(np.ascontiguousarray((np.asarray(mask).reshape(-1) != 0).astype(np.uint8)))
+    stage = None if src.is_pinned() else [pin((chunk, nte)), pin((chunk, nte))]
+    dv = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, device=dev)
+    with torch.cuda.device(dev):
+        s_in, s_fit, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        d_in = [dv((chunk, nte)), dv((chunk, nte))]
+        d_fa = [dv((chunk,)), dv((chunk,))]
+        d_mk = [dv((chunk,), torch.uint8), dv((chunk,), torch.uint8)] if mk_h is not None else [None, None]
+        d_out = [{"fsol": dv((chunk, nt2)), "sig": dv((chunk, nte)), "reg": dv((chunk,)), "lam": dv((chunk,)), "maps": dv((6, chunk)),
+                  "status": dv((chunk,), torch.int32)} for _ in range(2)]
+        ev_in = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_fit = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_out = [torch.cuda.Event(), torch.cuda.Event()]
+        s_in.wait_stream(torch.cuda.current_stream(dev))
+
+        def upload(c):
+            k = c & 1
+            lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
+            n = hi - lo
+            if c >= 2:
+                ev_fit[k].synchronize()            # the fit of chunk c - 2 has read this slot (its H2D finished long before)
+            if stage is not None:
+                stage[k][:n].copy_(src[lo:hi])      # pageable -> pinned (host memcpy)
+                h = stage[k][:n]
+            else:
+                h = src[lo:hi]
+            with torch.cuda.stream(s_in):
+                d_in[k][:n].copy_(h, non_blocking=True)
+                if fa_h is not None:
+                    d_fa[k][:n].copy_(fa_h[lo:hi], non_blocking=True)
+                if mk_h is not None:
+                    d_mk[k][:n].copy_(mk_h[lo:hi], non_blocking=True)
+                ev_in[k].record(s_in)
+
+        upload(0)
+        for c in range(nch):
+            k = c & 1
+            lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
+            n = hi - lo
+            if c + 1 < nch:
+                upload(c + 1)
+            with torch.cuda.stream(s_fit):
+                s_fit.wait_event(ev_in[k])
+                if c >= 2:
+                    s_fit.wait_event(ev_out[k])     # the outputs of chunk c - 2 have left this slot
+                o = d_out[k]
+                dd = d_in[k][:n]
+                mk = None if mk_h is None else d_mk[k][:n]
+                if fa_method == "brute-force":
+                    fa, _, _ = plan.fa_bruteforce(dd, mk)
+                    d_fa[k][:n].copy_(fa)
+                elif fa_h is None:
+                    d_fa[k][:n].zero_()
+                # the chunk's maps are [6, n]: a contiguous [6 * n] prefix of the slot's buffer viewed as [6, n]
+                maps_v = o["maps"].reshape(-1)[: 6 * n].view(6, n)
+                plan.fit(reg_method, dd, fa_index=d_fa[k][:n], mask=mk, sync=False,
+                         out={"fsol": o["fsol"][:n], "sig": o["sig"][:n], "reg": o["reg"][:n], "lam": o["lam"][:n], "maps": maps_v, "status": o["status"][:n]},
+                         want_lambda=True)
+                ev_fit[k].record(s_fit)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_fit[k])
+                res["fsol"][lo:hi].copy_(o["fsol"][:n], non_blocking=True)
+                res["sig"][lo:hi].copy_(o["sig"][:n], non_blocking=True)
+                res["reg"][lo:hi].copy_(o["reg"][:n], non_blocking=True)
+                res["status"][lo:hi].copy_(o["status"][:n], non_blocking=True)
+                res["fa_index"][lo:hi].copy_(d_fa[k][:n], non_blocking=True)
+                if want_lambda:
+                    res["lam"][lo:hi].copy_(o["lam"][:n], non_blocking=True)
+                for i in range(6):
+                    res["maps"][i, lo:hi].copy_(maps_v[i], non_blocking=True)
+                ev_out[k].record(s_out)
+        with torch.cuda.stream(s_fit):
+            plan.finish()
+        s_out.synchronize()
+        torch.cuda.current_stream(dev).wait_stream(s_fit)
+    return res
+
+
 def _prepare_volume(data, mask, dev, prepared, denoise):
     """The driver's preparation (motor:180-182, :279, :293-333) on the device.  The volume keeps the memory order it
     arrives in (nibabel arrays are Fortran-ordered; the solver reads either order in place)."""

@@ -183,10 +183,12 @@ class Met2Plan:
         return (t != 0).to(torch.uint8).contiguous() if dtype == torch.uint8 else t.to(dtype).contiguous()
 
     def fit(self, method, data, fa_index=None, mask=None, want_sig=True, want_maps=True, want_status=True, want_lambda=False,
-            out=None):
+            out=None, sync=True):
         """data [..., n_te] float64 cuda tensor: a voxel list [nvox, n_te] or a volume [nx, ny, nz, n_te], C- or
         Fortran-contiguous (see voxel_layout; neither is copied).  fa_index / mask: one entry per voxel, flat in the data's
-        voxel order or shaped like the volume.  Returns a dict of cuda tensors with the voxel axes of `data`."""
+        voxel order or shaped like the volume.  Returns a dict of cuda tensors with the voxel axes of `data`.
+        sync=False only enqueues the launches on the current stream (met2_fit_enqueue_strided): call finish() before the
+        outputs are read on the host; an FA index outside the dictionary is then reported by finish()."""
         if method not in METHODS:
             raise ValueError("unknown reg_method %r" % (method,))
         self._check_data(data)
@@ -210,13 +212,20 @@ class Met2Plan:
         lam = buf("lam", (nvox,)) if want_lambda else None
         maps = buf("maps", (6, nvox)) if want_maps else None
         status = buf("status", (nvox,), torch.int32) if want_status else None
+        entry = lib().met2_fit_strided if sync else lib().met2_fit_enqueue_strided
         with torch.cuda.device(dev):
-            check(lib().met2_fit_strided(self._h, METHODS[method], nvox, _ptr(data), vs, es, _ptr(fa_index), _ptr(mask), _ptr(fsol),
-                                         _ptr(sig), _ptr(reg), _ptr(lam), _ptr(maps), _ptr(status), self._stream()))
+            check(entry(self._h, METHODS[method], nvox, _ptr(data), vs, es, _ptr(fa_index), _ptr(mask), _ptr(fsol),
+                        _ptr(sig), _ptr(reg), _ptr(lam), _ptr(maps), _ptr(status), self._stream()))
         res = {"fsol": fsol, "sig": sig, "reg": reg, "lam": lam, "maps": maps, "status": status}
         if len(vol) > 1:
             res = {k: (None if t is None else unflatten(t, vol, order, lead=1 if k == "maps" else 0)) for k, t in res.items()}
         return res
+
+    def finish(self):
+        """Wait for the current stream and report what fits enqueued with sync=False deferred (met2_plan_finish)."""
+        with torch.cuda.device(self.device):
+            check(lib().met2_plan_finish(self._h, self._stream()))
+        return self
 
     def objective_grid(self, method, data, lams, fa_index=None):
         """Values of `method`'s lambda-selection objective at `lams` for every voxel -> [nvox, len(lams)].

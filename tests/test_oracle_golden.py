@@ -276,3 +276,21 @@ print("ASAN_OK")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and "ASAN_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
     assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-4000:]
+
+
+def test_scipy_restatement_against_reference_golden(gS1):
+    # bench.py's second CPU baseline (oracle/scipy_restatement.py: scipy.optimize.nnls inside fminbound, joblib over image rows --
+    # the reference's own software stack, written again) against the reference's outputs: nnls_x2 (algorithms.py:211-233) and
+    # nnls_tik (:262-269) voxel by voxel, and the row kernel (motor:113-162) through the joblib row split
+    from oracle import scipy_restatement as sr
+    g = gS1
+    D = g["D150"]; M = g["data"] / g["data"][:, :1]
+    for pen in ("L2", "I"):
+        L = g["L_" + pen]
+        for v in range(8):
+            f, lam, kest = sr.nnls_x2(D, M[v], L, 1.02)
+            assert relmax(f, g["x2_f_" + pen][v]) < 1e-9 and abs(lam - g["x2_lam_" + pen][v]) <= 1e-9 and abs(kest - g["x2_kest_" + pen][v]) < 1e-9
+        assert relmax(sr.nnls_tik(D, M[0], L, g["tik_lams"][2]), g["tik_" + pen][2, 0]) < 1e-9
+    fs, sg, rg = sr.fit_rows("X2", D, g["L_L2"], g["data"][:12], n_rows=3, n_jobs=2)
+    ref = np.stack([g["x2_f_L2"][v] * g["data"][v, 0] for v in range(12)])
+    assert np.max(relmax_rows(fs, ref)) < 1e-9 and np.allclose(rg, g["x2_kest_L2"][:12], rtol=1e-8)

@@ -1,6 +1,6 @@
 """Development probe: step through the HIP path on a handful of voxels with progress prints."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MET2_DEBUG", "1")
 import numpy as np, torch, faulthandler
 faulthandler.dump_traceback_later(150, repeat=False)
