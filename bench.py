@@ -197,15 +197,20 @@ def end_to_end(plan, pkg, method, data, brute, chunk_vox=131072, reps=2):
     host.copy_(data)
     torch.cuda.synchronize()
     best = None
-    for _ in range(reps):
+    out = None
+    first = None
+    for _ in range(reps + 1):                       # the first pass also pins the output buffers; the later ones write them again
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = motor.fit_host_pipeline(plan, method, host, fa_method="brute-force" if brute else None, chunk=chunk_vox)
+        out = motor.fit_host_pipeline(plan, method, host, fa_method="brute-force" if brute else None, chunk=chunk_vox, out=out)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        if first is None:
+            first = dt
+        else:
+            best = dt if best is None else min(best, dt)
     nbytes = host.numel() * 8 + sum(int(t.numel()) * t.element_size() for t in out.values() if torch.is_tensor(t))
-    return {"ms": 1e3 * best, "voxels_per_s": data.shape[0] / best, "chunk_voxels": chunk_vox, "host_bytes_moved": nbytes,
+    return {"ms": 1e3 * best, "first_call_ms": 1e3 * first, "voxels_per_s": data.shape[0] / best, "chunk_voxels": chunk_vox, "host_bytes_moved": nbytes,
             "pcie_GBps": nbytes / best / 1e9,
             "includes": "pinned host volume -> H2D -> %sfit + metrics -> D2H of fsol, Est_Signal, reg_param, maps (two streams, chunks of %d voxels)"
                         % ("brute-force FA -> " if brute else "", chunk_vox)}

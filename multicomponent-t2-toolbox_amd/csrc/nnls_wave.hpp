@@ -520,6 +520,7 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
         if (++iter > itmax) return false;
         double z[NB], xp[NB], zb[NB], ratio[NB];
         bool neg[NB];
+        if (MET2_DOUBLE == 4) { back_subst<NB>(S, st, lane, z); asm volatile("" :: "v"(z[0])); }
         back_subst<NB>(S, st, lane, z);                      // position-indexed
         bool any = false;
 #pragma unroll
@@ -591,6 +592,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
         if (st.k >= n || st.k >= mrows) break;
         double w[NB];
         MET2_CYC_BEGIN(c_du);
+        if (MET2_DOUBLE == 2) { dual<NB>(S, bd, st, lam, lane, w); asm volatile("" :: "v"(w[0])); }
         dual<NB>(S, bd, st, lam, lane, w);
         MET2_CYC_END(3, c_du);
         MET2_CYC_ADD(13, 1);
@@ -1051,10 +1053,17 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
 #ifndef MET2_REFACTOR_BLOCKED_FROM
 #define MET2_REFACTOR_BLOCKED_FROM 2        // bins per lane from which the blocked form is used
 #endif
+// -DMET2_DOUBLE=<phase> (development): an idempotent phase is executed twice -- 1 refactorisation, 2 dual, 3 model signal,
+// 4 back substitution -- so that the difference in kernel time against the plain build is that phase's MARGINAL cost (the share of
+// the wave cycles a phase takes says little when four waves per SIMD fill each other's waits)
+#ifndef MET2_DOUBLE
+#define MET2_DOUBLE 0
+#endif
 template <int NB>
 __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
     if (NB >= MET2_REFACTOR_BLOCKED_FROM) return refactor_blocked<NB>(S, bd, st, lam, lane);
+    if (MET2_DOUBLE == 1) { (void)refactor_rowwise<NB>(S, bd, st, lam, lane); __builtin_amdgcn_wave_barrier(); }
     return refactor_rowwise<NB>(S, bd, st, lam, lane);
 }
 
@@ -1127,6 +1136,7 @@ __device__ __forceinline__ double sse_of(const WaveShared &S, const NnlsState<NB
 #ifdef MET2_CYCSTATS
     const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
+    if (MET2_DOUBLE == 3) { const double r0 = model_signal<NB>(S, st, lane); asm volatile("" :: "v"(r0)); }
     double r = model_signal<NB>(S, st, lane) - b;
     r = (lane < S.m) ? r : 0.0;
     const double out = wave_sum(r * r);

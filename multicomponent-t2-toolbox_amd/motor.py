@@ -107,7 +107,7 @@ def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
     return out.cpu().numpy() if as_numpy else out
 
 
-def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=131072, want_lambda=False):
+def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=131072, want_lambda=False, out=None):
     """Driver steps 2-4 (motor:349-373, 427-472) for a voxel list that lives in HOST memory, as the reference's driver holds it
     (motor:167-182): chunks of `chunk` voxels go H2D on one stream, through [brute-force FA estimation and] the fit on a second,
     and the outputs D2H on a third, double-buffered, so that the copies of chunks c+1 and c-1 run under the fit of chunk c.  The
@@ -116,6 +116,8 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                 tensors) is staged through two pinned chunk buffers
       fa_method None (fa_index given, or flip angle 0 for all) | 'brute-force' (estimated per chunk on the device)
       fa_index, mask: host arrays [nvox] or None
+      out       a dict this function returned earlier for the same shapes: its pinned buffers are written again (pinning 0.8 GB of
+                host memory costs tens of ms; torch's caching host allocator does the same for buffers that were freed)
     Returns pinned CPU tensors: fsol [nvox, n_t2], sig [nvox, n_te], reg [nvox], maps [6, nvox], status [nvox] (int32), fa_index
     [nvox] and lam when asked; chunking changes nothing in them (every voxel is solved on its own)."""
     dev = plan.device
@@ -126,10 +128,15 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
     chunk = max(1, min(int(chunk), max(nvox, 1)))
     nch = (nvox + chunk - 1) // chunk
     pin = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True)
-    res = {"fsol": pin((nvox, nt2)), "sig": pin((nvox, nte)), "reg": pin((nvox,)), "maps": pin((6, nvox)), "status": pin((nvox,), torch.int32),
-           "fa_index": pin((nvox,))}
+    shapes = {"fsol": ((nvox, nt2), torch.float64), "sig": ((nvox, nte), torch.float64), "reg": ((nvox,), torch.float64),
+              "maps": ((6, nvox), torch.float64), "status": ((nvox,), torch.int32), "fa_index": ((nvox,), torch.float64)}
     if want_lambda:
-        res["lam"] = pin((nvox,))
+        shapes["lam"] = ((nvox,), torch.float64)
+    res = {}
+    for name, (shp, dt) in shapes.items():
+        t = None if out is None else out.get(name)
+        ok = t is not None and tuple(t.shape) == shp and t.dtype == dt and t.is_pinned() and t.is_contiguous()
+        res[name] = t if ok else pin(shp, dt)
     if nvox == 0:
         return res
     fa_h = None if fa_index is None else torch.from_numpy(np.ascontiguousarray(np.asarray(fa_index, dtype=np.float64).reshape(-1)))
