@@ -25,6 +25,16 @@
 
 namespace met2 {
 
+// -DMET2_DOUBLE=<phase> (development): an idempotent phase is executed twice -- 1 refactorisation, 2 dual, 3 model signal,
+// 4 back substitution -- so that the difference in kernel time against the plain build is that phase's MARGINAL cost (the share of
+// the wave cycles a phase takes says little when four waves per SIMD fill each other's waits)
+#ifndef MET2_DOUBLE
+#define MET2_DOUBLE 0
+#endif
+#ifndef MET2_REORDER
+#define MET2_REORDER 1        // 0: warm starts keep the order in which the bins entered (A/B builds)
+#endif
+
 #ifdef MET2_LOOPSTATS
 __device__ int g_loopstats[8];
 #define MET2_STAT(slot, v) atomicMax(&g_loopstats[slot], (int)(v))
@@ -310,7 +320,20 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
         int cbl[NB];                                                    // col_base of the lane's own (old) column
 #pragma unroll
         for (int b = 0; b < NB; ++b) cbl[b] = col_base(lane + 64 * b);
-        // rows above p: column c+1 moves into column c (all reads of a row, then its writes)
+        // rows above p: column c+1 moves into column c.  With the pivot order of reorder_by_x() the variable that leaves sits near the
+        // END of the order (k - 1 - p is 1 or 2): then the few columns behind p are moved one by one, lane <-> row; otherwise row by
+        // row, lane <-> column (all reads of a row, then its writes).
+        if (k - 1 - p < p) {
+            for (int c = p; c <= k - 2; ++c) {
+                const int src = col_base(c + 1), dst = col_base(c);
+                double v[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; v[b] = (pl < p) ? S.R[src + pl] : 0.0; }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; if (pl < p) S.R[dst + pl] = v[b]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else
         for (int i = 0; i < p; ++i) {
             double v[NB];
 #pragma unroll
@@ -1053,12 +1076,6 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
 #ifndef MET2_REFACTOR_BLOCKED_FROM
 #define MET2_REFACTOR_BLOCKED_FROM 2        // bins per lane from which the blocked form is used
 #endif
-// -DMET2_DOUBLE=<phase> (development): an idempotent phase is executed twice -- 1 refactorisation, 2 dual, 3 model signal,
-// 4 back substitution -- so that the difference in kernel time against the plain build is that phase's MARGINAL cost (the share of
-// the wave cycles a phase takes says little when four waves per SIMD fill each other's waits)
-#ifndef MET2_DOUBLE
-#define MET2_DOUBLE 0
-#endif
 template <int NB>
 __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
@@ -1075,6 +1092,61 @@ __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &
     nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
 }
 
+// Pivot order for a warm start: the passive bins by DESCENDING x.  The re-factorisation builds the factor in whatever order it is
+// given, so the order is free -- and it decides what a later exchange costs: removing position p re-triangularises the k - 1 - p
+// columns behind it (a chain of plane rotations, ~40 vector instructions each).  The bins that leave when lambda moves are the ones
+// whose coefficient is already small: measured on the reference's recipe (consecutive Brent abscissae, 150 voxels) the leaving bin is
+// the smallest-x bin of the set in 42 % of the removals and among the three smallest in 83 %, so with the smallest coefficients LAST
+// the chains have one or two links where the entering order (largest dual first) gave ~15.
+// Keys: the bit pattern of x (non-negative doubles order like unsigned integers) with its low 7 bits replaced by 127 - bin: all
+// different, so the ranks form a permutation whatever the data (any pivot order is valid; only the cost depends on it).  The new
+// position -> bin table goes through the wave's factor region, which the re-factorisation overwrites next.
+template <int NB>
+__device__ __forceinline__ void reorder_by_x(const WaveShared &S, NnlsState<NB> &st, int lane)
+{
+    const int k = st.k;
+    unsigned long long key[NB];
+    int rank[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = lane + 64 * b;
+        key[b] = ((unsigned long long)__double_as_longlong(st.x[b]) & ~127ull) | (unsigned long long)(127 - j);
+        rank[b] = 0;
+    }
+    u64 todo[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) todo[b] = st.P[b];
+#pragma unroll
+    for (int bs = 0; bs < NB; ++bs) {
+        u64 m = todo[bs];
+        while (m) {                                                  // every passive bin i: one broadcast of its key, one compare per lane
+            const int il = first_lane(m);
+            m &= m - 1ull;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key[bs], il);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key[bs] >> 32), il);
+            const unsigned long long ki = ((unsigned long long)hi << 32) | lo;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) rank[b] += (ki > key[b]) ? 1 : 0;
+        }
+    }
+    // bins outside the set take the positions behind it, in bin order: a full permutation of the 64 NB entries
+    int *tab = (int *)S.R;
+    int zbase = k;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool in = (st.P[b] >> lane) & 1ull;
+        const int below = __popcll(~st.P[b] & ((1ull << lane) - 1ull));
+        const int dst = in ? rank[b] : zbase + below;
+        tab[dst] = lane + 64 * b;
+        st.pos[b] = in ? rank[b] : -1;
+        zbase += 64 - __popcll(st.P[b]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) st.ord[b] = min(tab[lane + 64 * b], S.n - 1);    // positions past the set must still name valid bins (row loads in fours)
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Warm start: keep the previous solution's passive set and x (a feasible point for any lambda),
 // rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
 // strictly convex problem does not depend on the starting point, so this returns the same x as the
@@ -1085,6 +1157,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     const int kold = st.k;
     if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
+    if (MET2_REORDER && kold >= 4) reorder_by_x<NB>(S, st, lane);
     if (!refactor<NB>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
         int ordold[NB];
