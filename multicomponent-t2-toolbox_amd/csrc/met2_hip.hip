@@ -488,6 +488,9 @@ struct SeedRec {
     int k, pad[3];
 };
 
+#ifndef MET2_SEED_VOTE
+#define MET2_SEED_VOTE 31      // noisy copies of the canonical signal whose majority forms the seed set (0: the noise-free solve alone)
+#endif
 template <int NB>
 __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
 {
@@ -513,6 +516,48 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
     project<NB>(S, b, lane, st.h);
     nnls_solve<NB>(S, bd, st, A.lam[slot], true, lane);
     SeedRec *rec = (SeedRec *)A.out + ((size_t)slot * A.nfa + fa);
+#if MET2_SEED_VOTE
+    // The noise-free canonical signal keeps more bins than a measured one does (34 against 21-26 of 60 at the first Brent point of
+    // X2/L2 on the reference's SNR 50-150 recipe: every voxel then started by removing ~9 bins).  The seed set is therefore the
+    // MAJORITY VOTE over MET2_SEED_VOTE noisy copies of the canonical signal (Gaussian noise at 1 % of the first echo, a fixed
+    // counter-based generator: the seed stays a function of the plan alone), each solved warm from the previous one, and the seed
+    // iterate the mean of their solutions on that set -- a feasible point; which point it is only matters for speed.
+    const bool ok0 = st.itmax_hit == 0;
+    int votes[NB]; double xsum[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) { votes[bb] = 0; xsum[bb] = 0.0; }
+    for (int r = 0; r < MET2_SEED_VOTE; ++r) {
+        unsigned hsh = (unsigned)(r * 64 + lane) * 2654435761u + 0x9e3779b9u * (unsigned)(fa + 1);
+        hsh ^= hsh >> 15; hsh *= 0x2c1b3c6du; hsh ^= hsh >> 12; hsh *= 0x297a2d39u; hsh ^= hsh >> 15;
+        unsigned h2 = hsh * 747796405u + 2891336453u; h2 ^= h2 >> 16; h2 *= 0x85ebca6bu; h2 ^= h2 >> 13;
+        const double u1 = ((double)hsh + 0.5) * (1.0 / 4294967296.0), u2 = ((double)h2 + 0.5) * (1.0 / 4294967296.0);
+        const double gz = sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+        double bn = (lane < m) ? b + 0.01 * gz : 0.0;
+        bn = bn / bcast(bn, 0);
+        project<NB>(S, bn, lane, st.h);
+        nnls_solve_warm<NB>(S, bd, st, A.lam[slot], true, lane);
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) { votes[bb] += (st.x[bb] > 0.0) ? 1 : 0; xsum[bb] += st.x[bb]; }
+    }
+    int kk = 0, base = 0;
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        const bool in = (lane + 64 * bb < n) && (2 * votes[bb] > MET2_SEED_VOTE) && (xsum[bb] > 0.0);
+        const u64 msk = ballot(in);
+        const int rank = base + __popcll(msk & ((1ull << lane) - 1ull));
+        rec->x[lane + 64 * bb] = in ? xsum[bb] * (1.0 / MET2_SEED_VOTE) : 0.0;
+        votes[bb] = in ? rank : -1;                             // (reused: the bin's position)
+        rec->pos[lane + 64 * bb] = votes[bb];
+        base += __popcll(msk);
+    }
+    kk = base;
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        if (votes[bb] >= 0) rec->ord[votes[bb]] = lane + 64 * bb;     // positions in bin order (the fit kernel re-orders by x at its first warm start)
+        if (lane + 64 * bb >= kk) rec->ord[lane + 64 * bb] = 0;      // positions behind the set name a valid bin
+    }
+    if (lane == 0) rec->k = (ok0 && st.itmax_hit == 0) ? kk : 0;
+#else
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
         rec->x[lane + 64 * bb] = st.x[bb];
@@ -520,6 +565,7 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
         rec->ord[lane + 64 * bb] = st.ord[bb];
     }
     if (lane == 0) rec->k = (st.itmax_hit == 0) ? st.k : 0;
+#endif
 }
 
 #ifndef MET2_SEED

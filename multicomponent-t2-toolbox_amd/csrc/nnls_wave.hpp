@@ -1105,45 +1105,42 @@ template <int NB>
 __device__ __forceinline__ void reorder_by_x(const WaveShared &S, NnlsState<NB> &st, int lane)
 {
     const int k = st.k;
+    typedef __attribute__((address_space(3))) unsigned long long *lds_u64p;
+    unsigned long long *tabk = (unsigned long long *)S.R;          // [k + 4] keys by OLD position, zero padded (a zero key outranks nobody)
+    int *tabi = (int *)(tabk + k + 4);                             // [64 NB] new position -> bin
     unsigned long long key[NB];
-    int rank[NB];
+    bool in[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = lane + 64 * b;
+        in[b] = (st.P[b] >> lane) & 1ull;
         key[b] = ((unsigned long long)__double_as_longlong(st.x[b]) & ~127ull) | (unsigned long long)(127 - j);
-        rank[b] = 0;
+        if (in[b]) tabk[st.pos[b]] = key[b];
+        if (j >= k && j < k + 4) tabk[j] = 0ull;
     }
-    u64 todo[NB];
+    __builtin_amdgcn_wave_barrier();
+    // rank = number of passive bins with a larger key: k uniform-address LDS reads (independent of each other: no broadcast chain)
+    int rank[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) todo[b] = st.P[b];
+    for (int b = 0; b < NB; ++b) rank[b] = 0;
+#pragma clang loop unroll(disable)
+    for (int p = 0; p < k; p += 4) {
+        const unsigned long long k0 = tabk[p], k1 = tabk[p + 1], k2 = tabk[p + 2], k3 = tabk[p + 3];
 #pragma unroll
-    for (int bs = 0; bs < NB; ++bs) {
-        u64 m = todo[bs];
-        while (m) {                                                  // every passive bin i: one broadcast of its key, one compare per lane
-            const int il = first_lane(m);
-            m &= m - 1ull;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key[bs], il);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key[bs] >> 32), il);
-            const unsigned long long ki = ((unsigned long long)hi << 32) | lo;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) rank[b] += (ki > key[b]) ? 1 : 0;
-        }
+        for (int b = 0; b < NB; ++b) rank[b] += (int)(k0 > key[b]) + (int)(k1 > key[b]) + (int)(k2 > key[b]) + (int)(k3 > key[b]);
     }
     // bins outside the set take the positions behind it, in bin order: a full permutation of the 64 NB entries
-    int *tab = (int *)S.R;
     int zbase = k;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const bool in = (st.P[b] >> lane) & 1ull;
         const int below = __popcll(~st.P[b] & ((1ull << lane) - 1ull));
-        const int dst = in ? rank[b] : zbase + below;
-        tab[dst] = lane + 64 * b;
-        st.pos[b] = in ? rank[b] : -1;
+        tabi[in[b] ? rank[b] : zbase + below] = lane + 64 * b;
+        st.pos[b] = in[b] ? rank[b] : -1;
         zbase += 64 - __popcll(st.P[b]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int b = 0; b < NB; ++b) st.ord[b] = min(tab[lane + 64 * b], S.n - 1);    // positions past the set must still name valid bins (row loads in fours)
+    for (int b = 0; b < NB; ++b) st.ord[b] = min(tabi[lane + 64 * b], S.n - 1);   // positions past the set must still name valid bins (row loads in fours)
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -1157,7 +1154,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     const int kold = st.k;
     if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
-    if (MET2_REORDER && kold >= 4) reorder_by_x<NB>(S, st, lane);
+    if (MET2_REORDER && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
     if (!refactor<NB>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
         int ordold[NB];
