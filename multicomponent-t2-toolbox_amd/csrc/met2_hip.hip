@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void requeue_overflow_kernel(int64_t nvox, con
 // ------------------------------------------------------------------------------------------
 // fit kernel
 // ------------------------------------------------------------------------------------------
+#ifndef MET2_BAYES_TABLE
+#define MET2_BAYES_TABLE 10               // shared Brent abscissae with plan-level factors (0 disables the tables)
+#endif
 struct FitArgs {
     int n, m, nfa, kmax, waves, chunk;
     int wave_doubles;   // LDS doubles owned by each wave (>= kmax(kmax+1)/2; n*n for GCV)
@@ -261,6 +264,9 @@ struct FitArgs {
     int32_t *status;
     int64_t nvox;
     const char *seed;                     // [nfa] SeedRec: first-Brent-point seeds of the method (seed_kernel), or NULL
+    const double *btab;                   // BayesReg: [nfa][nbtab][btab_stride] factors of B + lambda_j K and, behind each, log det (bayes_table_kernel), or NULL
+    int nbtab, btab_stride;
+    double blam[MET2_BAYES_TABLE];        // the shared Brent abscissae lambda_j
 };
 
 // SciPy's bounded Brent (scipy.optimize.fminbound, called at algorithms.py:219,280 and
@@ -488,9 +494,6 @@ struct SeedRec {
     int k, pad[3];
 };
 
-#ifndef MET2_SEED_VOTE
-#define MET2_SEED_VOTE 31      // noisy copies of the canonical signal whose majority forms the seed set (0: the noise-free solve alone)
-#endif
 template <int NB>
 __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
 {
@@ -516,48 +519,6 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
     project<NB>(S, b, lane, st.h);
     nnls_solve<NB>(S, bd, st, A.lam[slot], true, lane);
     SeedRec *rec = (SeedRec *)A.out + ((size_t)slot * A.nfa + fa);
-#if MET2_SEED_VOTE
-    // The noise-free canonical signal keeps more bins than a measured one does (34 against 21-26 of 60 at the first Brent point of
-    // X2/L2 on the reference's SNR 50-150 recipe: every voxel then started by removing ~9 bins).  The seed set is therefore the
-    // MAJORITY VOTE over MET2_SEED_VOTE noisy copies of the canonical signal (Gaussian noise at 1 % of the first echo, a fixed
-    // counter-based generator: the seed stays a function of the plan alone), each solved warm from the previous one, and the seed
-    // iterate the mean of their solutions on that set -- a feasible point; which point it is only matters for speed.
-    const bool ok0 = st.itmax_hit == 0;
-    int votes[NB]; double xsum[NB];
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) { votes[bb] = 0; xsum[bb] = 0.0; }
-    for (int r = 0; r < MET2_SEED_VOTE; ++r) {
-        unsigned hsh = (unsigned)(r * 64 + lane) * 2654435761u + 0x9e3779b9u * (unsigned)(fa + 1);
-        hsh ^= hsh >> 15; hsh *= 0x2c1b3c6du; hsh ^= hsh >> 12; hsh *= 0x297a2d39u; hsh ^= hsh >> 15;
-        unsigned h2 = hsh * 747796405u + 2891336453u; h2 ^= h2 >> 16; h2 *= 0x85ebca6bu; h2 ^= h2 >> 13;
-        const double u1 = ((double)hsh + 0.5) * (1.0 / 4294967296.0), u2 = ((double)h2 + 0.5) * (1.0 / 4294967296.0);
-        const double gz = sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
-        double bn = (lane < m) ? b + 0.01 * gz : 0.0;
-        bn = bn / bcast(bn, 0);
-        project<NB>(S, bn, lane, st.h);
-        nnls_solve_warm<NB>(S, bd, st, A.lam[slot], true, lane);
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) { votes[bb] += (st.x[bb] > 0.0) ? 1 : 0; xsum[bb] += st.x[bb]; }
-    }
-    int kk = 0, base = 0;
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-        const bool in = (lane + 64 * bb < n) && (2 * votes[bb] > MET2_SEED_VOTE) && (xsum[bb] > 0.0);
-        const u64 msk = ballot(in);
-        const int rank = base + __popcll(msk & ((1ull << lane) - 1ull));
-        rec->x[lane + 64 * bb] = in ? xsum[bb] * (1.0 / MET2_SEED_VOTE) : 0.0;
-        votes[bb] = in ? rank : -1;                             // (reused: the bin's position)
-        rec->pos[lane + 64 * bb] = votes[bb];
-        base += __popcll(msk);
-    }
-    kk = base;
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-        if (votes[bb] >= 0) rec->ord[votes[bb]] = lane + 64 * bb;     // positions in bin order (the fit kernel re-orders by x at its first warm start)
-        if (lane + 64 * bb >= kk) rec->ord[lane + 64 * bb] = 0;      // positions behind the set name a valid bin
-    }
-    if (lane == 0) rec->k = (ok0 && st.itmax_hit == 0) ? kk : 0;
-#else
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
         rec->x[lane + 64 * bb] = st.x[bb];
@@ -565,7 +526,40 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
         rec->ord[lane + 64 * bb] = st.ord[bb];
     }
     if (lane == 0) rec->k = (st.itmax_hit == 0) ? st.k : 0;
-#endif
+}
+
+// Plan-level Cholesky factors for BayesReg's shared Brent abscissae (see BayesTable in objectives.hpp): one wave per (flip angle,
+// abscissa) factorises B + lambda_j K in LDS with the routine the fit kernel uses (chol_full, beta = 1) and stores the packed
+// triangle and log det U0 = sum log U0_ii.  A non-positive pivot stores NaN as log det: the fit kernel then sees NaN where the
+// reference would raise LinAlgError (bayesian_interpolation.py:115) -- same as its own factorisation failing.
+struct BayesTabArgs {
+    int n, m, nfa, nj, stride;
+    const double *Bfa, *Kd, *kband, *lband;
+    double lam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
+    double *out;
+};
+template <int NB>
+__global__ __launch_bounds__(64) void bayes_table_kernel(BayesTabArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = lane_id(), n = A.n, fa = (int)blockIdx.x, j = (int)blockIdx.y;
+    WaveShared S;
+    S.R = smem; S.n = n; S.m = A.m; S.kmax = n; S.rcap = col_base(n); S.K = A.Kd; S.kband = A.kband;
+    S.B = A.Bfa + (size_t)fa * n * n; S.D = nullptr; S.Dt = nullptr; S.DtG = nullptr;
+    S.bstride = n; S.dstride = n; S.dtstride = A.m; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    Band<NB> bd;
+    load_band<NB>(bd, A.kband, A.lband, lane);
+    double det_u;
+    const bool ok = chol_full<NB>(S, bd, 1.0, A.lam[j], lane, det_u);
+    __builtin_amdgcn_wave_barrier();
+    double *rec = A.out + ((size_t)fa * A.nj + j) * A.stride;
+    const int tri = col_base(n);
+    for (int i = lane; i < tri; i += 64) rec[i] = smem[i];
+    double ls = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { const int c = lane + 64 * b; if (c < n) ls += log(smem[col_base(c) + c]); }
+    ls = wave_sum(ls);
+    if (lane == 0) rec[A.stride - 1] = ok ? ls : NAN;
 }
 
 #ifndef MET2_SEED
@@ -768,11 +762,20 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
                 const double sigma = sqrt(sse_of<NB>(S, st, b, lane) / dof);
                 BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
-                int flag;
+                int flag, ev = 0;
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
-                    return bayes_objective<NB>(S, bd, st, bc, x, b, lane);
+                    BayesTable tab{nullptr, 0.0};
+                    if (A.btab && ev < A.nbtab) {                  // still on the abscissae every voxel shares?  (a rounding-level match: the table's
+                        const double tl = A.blam[ev];              //  lambda_j is formed on the host, and B + lambda K does not care about an ulp)
+                        if (fabs(x - tl) <= 1e-14 * tl) {
+                            const double *rec = A.btab + ((size_t)fa * A.nbtab + ev) * A.btab_stride;
+                            tab.U0 = rec; tab.logdet0 = rec[A.btab_stride - 1];
+                        }
+                    }
+                    ++ev;
+                    return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab);
                 }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
@@ -1382,6 +1385,8 @@ struct met2_plan {
     bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
     bool seeds_ok = false;                                // B + lambda K is positive definite at the seed lambdas (checked on the host for
                                                           // flip angle 0): only then is the seeded start the cold start's solution
+    double *dBtab = nullptr; int btab_stride = 0;         // BayesReg factor tables [nfa][MET2_BAYES_TABLE][btab_stride] (built with the seeds)
+    double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
     int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
     bool err_pending = false;
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
@@ -1764,6 +1769,33 @@ static int ensure_seeds(met2_plan *p, hipStream_t s)
         hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
     }
     HIPCHK(hipGetLastError());
+    if (MET2_BAYES_TABLE > 0) {
+        // BayesReg's shared abscissae on [1e-8, 2] (fminbound_dev with an objective that decreases towards the lower bound):
+        // a + g (b - a), one golden step up, then golden steps down
+        const double a = 1e-8, b = 2.0;
+        BayesTabArgs TA;
+        TA.n = n; TA.m = p->n_te; TA.nfa = p->n_fa; TA.nj = MET2_BAYES_TABLE;
+        TA.Bfa = p->dB; TA.Kd = p->dKd; TA.kband = p->dKband; TA.lband = p->dLband;
+        double t0 = a + gm * (b - a);
+        for (int j = 0; j < MET2_BAYES_TABLE; ++j) {
+            double t;
+            if (j == 0) t = t0;
+            else if (j == 1) t = t0 + gm * (b - t0);
+            else { const double prev = (j == 2) ? t0 : p->blam[j - 1]; t = prev + gm * (a - prev); }
+            p->blam[j] = t; TA.lam[j] = t;
+        }
+        p->btab_stride = col_base(n) + 1;
+        if (!p->dBtab) HIPCHK(hipMalloc(&p->dBtab, sizeof(double) * (size_t)p->n_fa * MET2_BAYES_TABLE * p->btab_stride));
+        TA.stride = p->btab_stride; TA.out = p->dBtab;
+        if (n <= 64) {
+            HIPCHK(hipFuncSetAttribute((const void *)bayes_table_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(bayes_table_kernel<1>, dim3(p->n_fa, MET2_BAYES_TABLE), dim3(64), lds, s, TA);
+        } else {
+            HIPCHK(hipFuncSetAttribute((const void *)bayes_table_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(bayes_table_kernel<2>, dim3(p->n_fa, MET2_BAYES_TABLE), dim3(64), lds, s, TA);
+        }
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(s));
     p->seeds_valid = true; p->seeds_t2sparc = p->opt.t2sparc_lambda;
     return MET2_OK;
@@ -1854,7 +1886,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed};
+    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -2148,6 +2180,11 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
         (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
         const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : 0);      // records built by ensure_seeds() when the plan was configured
         A.seed = p->dSeed + sizeof(SeedRec) * (size_t)slot * p->n_fa;
+    }
+    A.btab = nullptr; A.nbtab = 0; A.btab_stride = p->btab_stride;
+    for (int j = 0; j < (MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1); ++j) A.blam[j] = p->blam[j];
+    if (MET2_BAYES_TABLE > 0 && method == MET2_BAYESREG && !objgrid && p->dBtab && p->seeds_valid && p->seeds_ok && !tuning_env("MET2_NO_BAYES_TABLE", 0, 1, 0)) {
+        A.btab = p->dBtab; A.nbtab = MET2_BAYES_TABLE;
     }
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }

@@ -32,7 +32,7 @@ namespace met2 {
 #define MET2_DOUBLE 0
 #endif
 #ifndef MET2_REORDER
-#define MET2_REORDER 1        // 0: warm starts keep the order in which the bins entered (A/B builds)
+#define MET2_REORDER 0        // 1: warm starts re-order the passive set by descending x (reorder_by_x below; measured neutral, see there)
 #endif
 
 #ifdef MET2_LOOPSTATS
@@ -1098,6 +1098,9 @@ __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &
 // whose coefficient is already small: measured on the reference's recipe (consecutive Brent abscissae, 150 voxels) the leaving bin is
 // the smallest-x bin of the set in 42 % of the removals and among the three smallest in 83 %, so with the smallest coefficients LAST
 // the chains have one or two links where the entering order (largest dual first) gave ~15.
+// MEASURED (round 3, configs[1]): the removals' wave cycles fell 6x (5.4 k -> 0.9 k per Brent evaluation) but the kernel did not
+// get faster (147.5 vs 147.7 ms) and its vector-instruction count barely moved (60.7 k -> 60.5 k per voxel): the chains were long in
+// latency (an LDS round trip per link), not in instructions, and the kernel is bound by vector-instruction issue.  Off by default.
 // Keys: the bit pattern of x (non-negative doubles order like unsigned integers) with its low 7 bits replaced by 127 - bin: all
 // different, so the ranks form a permutation whatever the data (any pivot order is valid; only the cost depends on it).  The new
 // position -> bin table goes through the wave's factor region, which the re-factorisation overwrites next.

@@ -196,23 +196,35 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
     return true;
 }
 
-// (U f)_i for the factor in S.R; the owner of row i gets row i . f
+// (U f)_i for a factor packed by columns at `U` (the wave's LDS region, or a plan-level table in global memory); the owner of row i
+// gets row i . f.  Only the columns of the passive bins are visited -- f is zero elsewhere (k ~ 20 of n = 60 columns).
 template <int NB>
-__device__ __forceinline__ void upper_times(const WaveShared &S, const double (&f)[NB], int lane, double (&out)[NB])
+__device__ __forceinline__ void upper_times(const double *U, const NnlsState<NB> &st, int lane, double (&out)[NB])
 {
-    const int n = S.n;
 #pragma unroll
     for (int b = 0; b < NB; ++b) out[b] = 0.0;
-    int cbj = 0;
-    for (int j = 0; j < n; ++j) {
-        const double fj = bcastN<NB>(f, j);
+    const int k = st.k;
+#pragma clang loop unroll(disable)
+    for (int p = 0; p < k; p += 4) {                                    // four columns in flight (positions past the set carry f = 0)
+        double u[4][NB], fj[4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = lane + 64 * b;
-            double u = (i <= j) ? S.R[cbj + i] : 0.0;                   // column j: rows 0..j
-            out[b] = fma(u, fj, out[b]);
+        for (int q = 0; q < 4; ++q) {
+            const int j = bcastN_i<NB>(st.ord, p + q);
+            const int cbj = col_base(j);
+            const double fv = bcastN<NB>(st.x, j);
+            fj[q] = (p + q < k) ? fv : 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int i = lane + 64 * b;
+                u[q][b] = U[cbj + min(i, j)];                           // column j: rows 0..j (clamped reads, masked below)
+            }
         }
-        cbj += col_len(j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = bcastN_i<NB>(st.ord, p + q);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) out[b] = fma((lane + 64 * b <= j) ? u[q][b] : 0.0, fj[q], out[b]);
+        }
     }
 }
 
@@ -221,30 +233,56 @@ struct BayesCtx {
     int failed;     // Cholesky failure seen
 };
 
+// Plan-level factors for the shared Brent abscissae (bayes_table_kernel): U0 = chol(B + lambda_j K) and log det U0 per flip angle.
+// The matrix the reference factorises at every evaluation, beta (B + lambda K) (bayesian_interpolation.py:113-115), depends on the
+// voxel through the scalar beta alone: chol(beta A) = sqrt(beta) chol(A).  scipy's bounded Brent visits the same abscissae
+// a + 0.382 (b - a), then the golden-section points towards the lower bound, for every voxel until its first accepted parabolic
+// step (6-10 of the ~17 evaluations of a voxel); at those the factor comes from the table: (U f) = sqrt(beta) (U0 f) and
+// log det U = log det U0 + (n / 2) log beta -- no factorisation (it was ~50 % of the BayesReg kernel).
+struct BayesTable {
+    const double *U0;       // packed factor of this (flip angle, abscissa), or NULL: factorise in LDS
+    double logdet0;
+};
+
 // bayesian_interpolation.py:107-126, given the NNLS solution st.x at lambda = x
 template <int NB>
 __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, BayesCtx &bc,
-                                                  double x, double b, int lane)
+                                                  double x, double b, int lane, BayesTable tab = BayesTable{nullptr, 0.0})
 {
     const int n = S.n, m = S.m;
     const double beta = bc.beta;
     const double ED = 0.5 * sse_of<NB>(S, st, b, lane);
     const double EW = 0.5 * seminorm2<NB>(bd, st.x, n, lane);
-    double det_u;
+    double log_det_u;
+    double uf[NB];
 #ifdef MET2_CYCSTATS
     NnlsState<NB> &stw = const_cast<NnlsState<NB> &>(st);
     const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
-    if (!chol_full<NB>(S, bd, beta, x, lane, det_u)) { bc.failed = 1; return NAN; }
+    if (tab.U0) {
+        upper_times<NB>(tab.U0, st, lane, uf);
+        const double sb = sqrt(beta);
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) uf[bb] *= sb;
+        log_det_u = tab.logdet0 + 0.5 * (double)n * log(beta);
 #ifdef MET2_CYCSTATS
-    const unsigned long long c1 = __builtin_readcyclecounter();
-    stw.cyc[5] += c1 - c0;
+        stw.cyc[6] += __builtin_readcyclecounter() - c0;
 #endif
-    double uf[NB];
-    upper_times<NB>(S, st.x, lane, uf);
+    } else {
+        double det_u;
+        if (!chol_full<NB>(S, bd, beta, x, lane, det_u)) { bc.failed = 1; return NAN; }
+#ifdef MET2_CYCSTATS
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        stw.cyc[5] += c1 - c0;
+#endif
+        upper_times<NB>(S.R, st, lane, uf);
+        log_det_u = log(det_u);
+#ifdef MET2_CYCSTATS
+        stw.cyc[6] += __builtin_readcyclecounter() - c1;
+#endif
+    }
 #ifdef MET2_CYCSTATS
     const unsigned long long c2 = __builtin_readcyclecounter();
-    stw.cyc[6] += c2 - c1;
 #endif
     double term = 0.0;
 #pragma unroll
@@ -254,7 +292,7 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
     stw.cyc[7] += __builtin_readcyclecounter() - c2;
 #endif
     const double PI = M_PI;
-    double cost1 = beta * ED + beta * x * EW + log(det_u) - (n / 2.0) * log(PI / 2.0) - series;
+    double cost1 = beta * ED + beta * x * EW + log_det_u - (n / 2.0) * log(PI / 2.0) - series;
     double cost2 = (m / 2.0) * log(2.0 * PI) - (m / 2.0) * log(beta) + (n / 2.0) * log(PI) - (n / 2.0) * log(2 * beta * x) - bc.log_detL;
     return cost1 + cost2;
 }

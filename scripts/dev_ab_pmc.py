@@ -10,7 +10,7 @@ bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", 
 for defs in sys.argv[1:]:
     env = dict(os.environ, MET2_BUILD_DEFINES="-DMET2_ONLY=2 " + defs, TMPDIR="/tmp")
     subprocess.check_call(["python3", "-c", "import importlib; importlib.import_module('multicomponent-t2-toolbox_amd._build').build(force=True)"], cwd=ROOT, env=env)
-    p = subprocess.run(bench[:3] + ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"], capture_output=True, text=True, env=env, cwd=ROOT)
+    p = subprocess.run(bench[:2] + ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"], capture_output=True, text=True, env=env, cwd=ROOT)
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     d = "/tmp/abpmc_%d" % abs(hash(defs))
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + CTRS + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + bench, cwd="/tmp", env=env,
