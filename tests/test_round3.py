@@ -196,3 +196,27 @@ def test_chunked_host_pipeline_equals_the_one_shot_fit(pinned):
     again = plan.fit("X2", data[:64], fa_index=fa[:64])                 # and the plan is usable afterwards
     assert torch.equal(again["fsol"], plan.fit("X2", data[:64], fa_index=fa[:64])["fsol"])
     plan.close()
+
+
+@pytest.mark.gpu
+def test_singular_penalty_runs_unseeded_and_fits_like_the_oracle(oracle):
+    # a penalty whose null space meets the dictionary's (35 zero rows: dim null(L) + dim null(D) > n): B + lambda K is singular, the
+    # minimiser is not unique, so the plan-level seeds (and BayesReg's factor tables) must not be used -- ensure_seeds() checks
+    # positive definiteness on the host.  What IS unique is the fitted signal D x and the penalty term: those must match the oracle.
+    import torch
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2, nvox = 32, 60, 512
+    T2s = synth.t2_grid(nt2)
+    L = np.diag(np.concatenate([np.ones(25), np.zeros(35)]))
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, 1000.0 * np.ones(nt2), 10.0, np.array([150.0]), 3000.0).set_penalty(L)
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=31, device="cuda")
+    out = plan.fit("T2SPARC", data)
+    D = oracle.dictionary_fa_major(nt2, T2s, 1000.0 * np.ones(nt2), nte, 10.0, [150.0], 3000.0)
+    fs, sg, rg, st = oracle.fit_batch("T2SPARC", D, L, data.cpu().numpy(), np.zeros(nvox), np.ones(nvox))
+    sig = out["sig"].cpu().numpy()
+    assert np.max(np.abs(sig - sg) / np.max(np.abs(sg), axis=1, keepdims=True)) < 1e-7
+    pen = lambda f: np.sum((f @ L.T) ** 2, axis=1)
+    assert np.allclose(pen(out["fsol"].cpu().numpy()), pen(fs), rtol=1e-6, atol=1e-12)
+    plan.close()
