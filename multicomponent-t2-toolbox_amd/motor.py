@@ -107,29 +107,38 @@ def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
     return out.cpu().numpy() if as_numpy else out
 
 
-def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=131072, want_lambda=False, out=None):
+def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=131072, want_lambda=False, out=None,
+                      echo_major=False, mask_values=None):
     """Driver steps 2-4 (motor:349-373, 427-472) for a voxel list that lives in HOST memory, as the reference's driver holds it
-    (motor:167-182): chunks of `chunk` voxels go H2D on one stream, through [brute-force FA estimation and] the fit on a second,
-    and the outputs D2H on a third, double-buffered, so that the copies of chunks c+1 and c-1 run under the fit of chunk c.  The
-    fits are only enqueued (met2_fit_enqueue_strided); one met2_plan_finish at the end waits and reports.
-      host_data [nvox, n_te] float64: a pinned torch CPU tensor is copied from in place; pageable memory (numpy arrays, ordinary
-                tensors) is staged through two pinned chunk buffers
-      fa_method None (fa_index given, or flip angle 0 for all) | 'brute-force' (estimated per chunk on the device)
-      fa_index, mask: host arrays [nvox] or None
+    (motor:167-182): chunks of `chunk` voxels go H2D on one stream, through [FA estimation and] the fit on a second, and the
+    outputs D2H on a third, double-buffered, so that the copies of chunks c+1 and c-1 run under the fit of chunk c.  The fits are
+    only enqueued (met2_fit_enqueue_strided); one met2_plan_finish at the end waits and reports.
+      host_data [nvox, n_te] float64 (or [n_te, nvox] with echo_major=True: the flattened Fortran-ordered volume nibabel hands the
+                driver): a pinned torch CPU tensor is copied from in place; pageable memory (numpy arrays, ordinary tensors) is
+                staged through two pinned chunk buffers
+      fa_method None (fa_index given, or flip angle 0 for all) | 'brute-force' | a callable (chunk [n, n_te] view on the device, mask
+                chunk or None) -> float64 FA-index tensor [n] (the spline method of recon_met2_arrays)
+      fa_index, mask: host arrays [nvox] or None; mask gates (mask != 0)
+      mask_values  host array [nvox]: the driver's preparation on the device -- every echo is multiplied by it and negative values are
+                clipped to 0 (motor:180-182, :279) before anything else sees the chunk
       out       a dict this function returned earlier for the same shapes: its pinned buffers are written again (pinning 0.8 GB of
                 host memory costs tens of ms; torch's caching host allocator does the same for buffers that were freed)
     Returns pinned CPU tensors: fsol [nvox, n_t2], sig [nvox, n_te], reg [nvox], maps [6, nvox], status [nvox] (int32), fa_index
-    [nvox] and lam when asked; chunking changes nothing in them (every voxel is solved on its own)."""
+    [nvox], fa_gate [nvox] (1 where the FA step's gate holds, fa_estimation.py:45: mask and a positive echo sum) and lam when asked;
+    chunking changes nothing in them (every voxel is solved on its own)."""
     dev = plan.device
-    src = host_data if torch.is_tensor(host_data) else torch.from_numpy(np.ascontiguousarray(host_data, dtype=np.float64))
-    if src.is_cuda or src.dtype != torch.float64 or src.dim() != 2 or src.shape[1] != plan.n_te or not src.is_contiguous():
-        raise ValueError("host_data must be a contiguous float64 [nvox, n_te=%d] array in host memory" % plan.n_te)
-    nvox, nte, nt2 = int(src.shape[0]), plan.n_te, plan.n_t2
+    src = host_data if torch.is_tensor(host_data) else torch.from_numpy(host_data)
+    nte, nt2 = plan.n_te, plan.n_t2
+    ok_shape = src.dim() == 2 and src.shape[0 if echo_major else 1] == nte
+    if src.is_cuda or src.dtype != torch.float64 or not ok_shape or not src.is_contiguous():
+        raise ValueError("host_data must be a contiguous float64 %s array in host memory" % ("[n_te=%d, nvox]" % nte if echo_major else "[nvox, n_te=%d]" % nte))
+    nvox = int(src.shape[1 if echo_major else 0])
     chunk = max(1, min(int(chunk), max(nvox, 1)))
     nch = (nvox + chunk - 1) // chunk
     pin = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True)
     shapes = {"fsol": ((nvox, nt2), torch.float64), "sig": ((nvox, nte), torch.float64), "reg": ((nvox,), torch.float64),
-              "maps": ((6, nvox), torch.float64), "status": ((nvox,), torch.int32), "fa_index": ((nvox,), torch.float64)}
+              "maps": ((6, nvox), torch.float64), "status": ((nvox,), torch.int32), "fa_index": ((nvox,), torch.float64),
+              "fa_gate": ((nvox,), torch.float64)}
     if want_lambda:
         shapes["lam"] = ((nvox,), torch.float64)
     res = {}
@@ -139,15 +148,21 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
         res[name] = t if ok else pin(shp, dt)
     if nvox == 0:
         return res
-    fa_h = None if fa_index is None else torch.from_numpy(np.ascontiguousarray(np.asarray(fa_index, dtype=np.float64).reshape(-1)))
+    as1d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(dt, copy=False)))
+    fa_h = None if fa_index is None else as1d(fa_index, np.float64)
     mk_h = None if mask is None else torch.from_numpy(np.ascontiguousarray((np.asarray(mask).reshape(-1) != 0).astype(np.uint8)))
-    stage = None if src.is_pinned() else [pin((chunk, nte)), pin((chunk, nte))]
+    mv_h = None if mask_values is None else as1d(mask_values, np.float64)
+    in_shape = (nte, chunk) if echo_major else (chunk, nte)
+    stage = None if src.is_pinned() else [pin(in_shape), pin(in_shape)]
     dv = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, device=dev)
+    cut = (lambda t, n: t[:, :n]) if echo_major else (lambda t, n: t[:n])         # the first n voxels of a chunk buffer
     with torch.cuda.device(dev):
         s_in, s_fit, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        d_in = [dv((chunk, nte)), dv((chunk, nte))]
+        d_in = [dv(in_shape), dv(in_shape)]
         d_fa = [dv((chunk,)), dv((chunk,))]
+        d_gate = [dv((chunk,)), dv((chunk,))]
         d_mk = [dv((chunk,), torch.uint8), dv((chunk,), torch.uint8)] if mk_h is not None else [None, None]
+        d_mv = [dv((chunk,)), dv((chunk,))] if mv_h is not None else [None, None]
         d_out = [{"fsol": dv((chunk, nt2)), "sig": dv((chunk, nte)), "reg": dv((chunk,)), "lam": dv((chunk,)), "maps": dv((6, chunk)),
                   "status": dv((chunk,), torch.int32)} for _ in range(2)]
         ev_in = [torch.cuda.Event(), torch.cuda.Event()]
@@ -161,17 +176,18 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
             n = hi - lo
             if c >= 2:
                 ev_fit[k].synchronize()            # the fit of chunk c - 2 has read this slot (its H2D finished long before)
+            h = src[:, lo:hi] if echo_major else src[lo:hi]
             if stage is not None:
-                stage[k][:n].copy_(src[lo:hi])      # pageable -> pinned (host memcpy)
-                h = stage[k][:n]
-            else:
-                h = src[lo:hi]
+                cut(stage[k], n).copy_(h)           # pageable -> pinned (host memcpy, one segment per echo when echo-major)
+                h = cut(stage[k], n)
             with torch.cuda.stream(s_in):
-                d_in[k][:n].copy_(h, non_blocking=True)
+                cut(d_in[k], n).copy_(h, non_blocking=True)
                 if fa_h is not None:
                     d_fa[k][:n].copy_(fa_h[lo:hi], non_blocking=True)
                 if mk_h is not None:
                     d_mk[k][:n].copy_(mk_h[lo:hi], non_blocking=True)
+                if mv_h is not None:
+                    d_mv[k][:n].copy_(mv_h[lo:hi], non_blocking=True)
                 ev_in[k].record(s_in)
 
         upload(0)
@@ -186,11 +202,19 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                 if c >= 2:
                     s_fit.wait_event(ev_out[k])     # the outputs of chunk c - 2 have left this slot
                 o = d_out[k]
-                dd = d_in[k][:n]
+                raw = cut(d_in[k], n)
+                if mv_h is not None:                # motor:180-182, :279 on the device, in place
+                    raw.mul_(d_mv[k][:n].unsqueeze(0) if echo_major else d_mv[k][:n].unsqueeze(1))
+                    raw.clamp_(min=0.0)
+                dd = raw.t() if echo_major else raw # [n, n_te] either way (echo-major: a strided view, read in place when the chunk is full)
                 mk = None if mk_h is None else d_mk[k][:n]
+                gate = dd.sum(dim=1) > 0
+                d_gate[k][:n].copy_(gate if mk is None else (gate & (mk != 0)))
                 if fa_method == "brute-force":
                     fa, _, _ = plan.fa_bruteforce(dd, mk)
                     d_fa[k][:n].copy_(fa)
+                elif callable(fa_method):
+                    d_fa[k][:n].copy_(fa_method(dd, mk))
                 elif fa_h is None:
                     d_fa[k][:n].zero_()
                 # the chunk's maps are [6, n]: a contiguous [6 * n] prefix of the slot's buffer viewed as [6, n]
@@ -206,6 +230,7 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                 res["reg"][lo:hi].copy_(o["reg"][:n], non_blocking=True)
                 res["status"][lo:hi].copy_(o["status"][:n], non_blocking=True)
                 res["fa_index"][lo:hi].copy_(d_fa[k][:n], non_blocking=True)
+                res["fa_gate"][lo:hi].copy_(d_gate[k][:n], non_blocking=True)
                 if want_lambda:
                     res["lam"][lo:hi].copy_(o["lam"][:n], non_blocking=True)
                 for i in range(6):
@@ -283,6 +308,9 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     nt = data.shape[-1]
     mask = np.asarray(mask).reshape(vol_shape)
     dev = plan.device if plan is not None else torch.device("cuda", device)
+    plain = denoise in ("None", None, "none") and not (FA_smooth == "yes" and fa_index is None) and not distributed and not return_prepared
+    if plain and data.ndim >= 2 and (data.flags.c_contiguous or data.flags.f_contiguous):
+        return _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, device, plan, prepared)
     dd, mk = _prepare_volume(data, mask, dev, prepared, denoise)
     dd_fa = dd
     if FA_smooth == "yes" and fa_index is None:
@@ -319,6 +347,62 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
             res["data_prepared"] = dd.cpu().numpy()
         return res
     finally:
+        if own:
+            plan.close()
+
+
+PIPELINE_CHUNK = 131072       # voxels per chunk of the driver's host pipeline (33 MB in, 100 MB out at 32 echoes / 60 bins)
+
+
+def _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, device, plan, prepared):
+    """recon_met2_arrays without denoising or FA smoothing (nothing needs the whole volume at once): the host volume streams through
+    fit_host_pipeline in its own memory order -- C-ordered [.., nt] voxel-major, Fortran-ordered (nibabel's) echo-major -- and the
+    outputs land in pinned host buffers that are returned as numpy views, reshaped to the volume.  Same numbers as the one-shot
+    path (`test_driver_pipeline_equals_one_shot`)."""
+    from .plan import unflatten
+    vol_shape = data.shape[:-1]
+    nt = data.shape[-1]
+    nvox = int(np.prod(vol_shape))
+    order = "C" if data.flags.c_contiguous else "F"
+    TE_array = np.asarray(TE_array, dtype=np.float64)
+    tau = float(TE_array[1] - TE_array[0])
+    Npc = 96 if reg_method == "T2SPARC" else 60
+    T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=Npc, endpoint=True, base=10.0)
+    T1s = 1000.0 * np.ones_like(T2s)
+    alpha_values = np.linspace(90.0, 180.0, 91 * 3 if FA_method == "spline" else 91)      # motor:231-244
+    flat = (lambda a: np.asarray(a).reshape(-1, order=order))                               # per-voxel arrays in the data's voxel order
+    src = data.reshape(nvox, nt) if order == "C" else data.reshape(nvox, nt, order="F").T   # views: [nvox, nt] or echo-major [nt, nvox]
+    mvals = None if prepared else flat(mask).astype(np.float64)
+    own = plan is None
+    plan_lr = None
+    if own:
+        plan = Met2Plan(nt, Npc, alpha_values.shape[0], device=device, myelin_T2=myelin_T2)
+        plan.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
+        plan.set_penalty("InvT2" if reg_method == "T2SPARC" else reg_matrix, T2s)   # run_real_data_script.py:91-93
+    try:
+        fa_m = None
+        if fa_index is None:
+            if FA_method == "spline":
+                alpha_lr = np.linspace(90.0, 180.0, 15)                                     # motor:237
+                plan_lr = Met2Plan(plan.n_te, plan.n_t2, 15, device=plan.device.index or 0)
+                plan_lr.build_dictionary_epg(T2s, T1s, tau, alpha_lr, TR)
+                fa_m = lambda dd, mk: plan.fa_spline(plan_lr, alpha_lr, alpha_values, dd, mk, want_km=False)[0]
+            else:
+                fa_m = "brute-force"
+        out = fit_host_pipeline(plan, reg_method, src, fa_method=fa_m, fa_index=None if fa_index is None else flat(fa_index),
+                                mask=flat(mask) > 0, chunk=PIPELINE_CHUNK, echo_major=(order == "F"), mask_values=mvals)
+        vol = lambda t, lead=0: unflatten(t, vol_shape, order, lead=lead).numpy()
+        res = {"fsol_4D": vol(out["fsol"]), "Est_Signal": vol(out["sig"]), "reg_param": vol(out["reg"]), "FA_index": vol(out["fa_index"])}
+        fitted_fa = vol(out["fa_gate"]) > 0                    # gate of the FA step (fa_estimation.py:45), formed on the prepared chunk
+        res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
+        maps = vol(out["maps"], lead=1)
+        for i, name in enumerate(MAP_NAMES):
+            res[name] = maps[i]
+        res["T2s"] = T2s
+        return res
+    finally:
+        if plan_lr is not None:
+            plan_lr.close()
         if own:
             plan.close()
 

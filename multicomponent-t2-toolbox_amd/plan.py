@@ -37,7 +37,7 @@ def voxel_layout(data, n_te):
         nvox *= int(d)
     if data.is_contiguous():
         return data, nvox, n_te, 1, vol, "C"
-    if data.dim() > 2 and data.permute(*reversed(range(data.dim()))).is_contiguous():
+    if data.permute(*reversed(range(data.dim()))).is_contiguous():       # (also an echo-major voxel list: a transposed [n_te, nvox] array)
         return data, nvox, 1, nvox, vol, "F"
     return data.contiguous(), nvox, n_te, 1, vol, "C"
 

@@ -220,3 +220,34 @@ def test_singular_penalty_runs_unseeded_and_fits_like_the_oracle(oracle):
     pen = lambda f: np.sum((f @ L.T) ** 2, axis=1)
     assert np.allclose(pen(out["fsol"].cpu().numpy()), pen(fs), rtol=1e-6, atol=1e-12)
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order,fa_method", [("C", "brute-force"), ("F", "brute-force"), ("F", "spline")])
+def test_driver_pipeline_equals_one_shot(order, fa_method):
+    # recon_met2_arrays streams a plain run (no denoising, no FA smoothing) through the chunked host pipeline; return_prepared=True
+    # takes the one-shot path (whole volume on the device).  Same ten outputs bit for bit, for C- and Fortran-ordered (nibabel)
+    # volumes, with zero and non-unit mask values, negative samples (clipped, motor:279) and a ragged last chunk.
+    import torch
+    motor = importlib.import_module(PKG + ".motor")
+    synth = importlib.import_module(PKG + ".synth")
+    dims = (13, 11, 9)
+    nvox = int(np.prod(dims))
+    alphas = np.linspace(90.0, 180.0, 91)
+    data, _, _ = synth.make_voxels(nvox, nte=32, seed=77, fa_values=alphas, device="cuda")
+    vol = data.cpu().numpy().reshape(dims + (32,))
+    rng = np.random.default_rng(3)
+    vol[rng.integers(0, 13, 20), rng.integers(0, 11, 20), rng.integers(0, 9, 20), rng.integers(0, 32, 20)] *= -1.0
+    mask = np.ones(dims, dtype=np.int64); mask[::4, ::3, :] = 0; mask[1, 1, 1] = 2
+    if order == "F":
+        vol = np.asfortranarray(vol)
+    TE = 10.0 * np.arange(1, 33)
+    keep = motor.PIPELINE_CHUNK
+    try:
+        motor.PIPELINE_CHUNK = 500                                  # 1287 voxels -> three chunks, the last one ragged
+        got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0)
+    finally:
+        motor.PIPELINE_CHUNK = keep
+    ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, return_prepared=True)
+    for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
+        assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k
