@@ -866,7 +866,73 @@ struct FaArgs {
     double *fa_index, *km, *resid;
     int *queue;
     int64_t nvox;
+    const double *H;          // [nvox of this pass][nfa * n]: h = D_fa^T b of every flip angle (fa_project_kernel), or NULL: formed in the walk
+    int64_t v0;               // first voxel of this pass (H row 0), voxels [v0, v0 + nvox_pass)
+    int64_t v_end;            // one past the last voxel of this pass
 };
+
+// ------------------------------------------------------------------------------------------
+// The batched contraction of the brute-force FA step on the matrix cores: every NNLS of fa_estimation.py:78-82 starts from
+// h_fa = D_fa^T b, 91 dictionaries per voxel.  As ONE GEMM per pass of voxels,  H[v][fa * n + bin] = sum_e data[v][e] D^T[fa][bin][e]
+// ([T x m] . [m x nfa n]) with v_mfma_f64_16x16x4: a wave keeps the echoes of 32 voxels in registers (two 16-voxel operand sets),
+// walks the nfa * n rows of the stacked D^T in tiles of 16 -- each tile's operand is loaded once from L2 and used for both voxel
+// sets -- and writes the 16 x 16 results voxel-major, so that the walk reads its h as one contiguous row per flip angle.
+// The walk without it re-derives h per (voxel pair, flip angle) on the vector unit from D rows streamed through L2 (half of the
+// 2.8 MB per voxel the FA walk pulls through L2 at 48 x 120).
+// KS = ceil(m / 4) k-steps of four echoes (operands past m are zero).
+// ------------------------------------------------------------------------------------------
+struct FaGemmArgs {
+    int n, m, nfa;
+    const double *Dtfa;       // [nfa * n][m]
+    const double *data; int64_t vs, es;
+    double *H;                // [T][nfa * n]
+    int64_t v0, v_end;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void fa_project_kernel(FaGemmArgs A)
+{
+    const int lane = lane_id(), li = lane & 15, lk = lane >> 4;
+    const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t vA = A.v0 + wv * 32;
+    if (vA >= A.v_end) return;
+    const int M = A.nfa * A.n, m = A.m;
+    // A operands: voxel vA + li (and vA + 16 + li), echoes 4 q + lk
+    double a0[KS], a1[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+        const int e = 4 * q + lk;
+        const int64_t v0 = vA + li, v1 = vA + 16 + li;
+        a0[q] = (e < m && v0 < A.v_end) ? A.data[v0 * A.vs + e * A.es] : 0.0;
+        a1[q] = (e < m && v1 < A.v_end) ? A.data[v1 * A.vs + e * A.es] : 0.0;
+    }
+    double *Hrow0[4], *Hrow1[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        Hrow0[v] = A.H + (size_t)(vA - A.v0 + lk + 4 * v) * M;
+        Hrow1[v] = A.H + (size_t)(vA - A.v0 + 16 + lk + 4 * v) * M;
+    }
+    for (int r0 = 0; r0 < M; r0 += 16) {
+        const int r = min(r0 + li, M - 1);
+        const double *drow = A.Dtfa + (size_t)r * m;
+        double bop[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) { const int e = 4 * q + lk; bop[q] = (e < m) ? drow[min(e, m - 1)] : 0.0; }
+        met2_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], bop[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], bop[q], acc1, 0, 0, 0);
+        }
+        if (r0 + li < M) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (vA + lk + 4 * v < A.v_end) Hrow0[v][r0 + li] = acc0[v];
+                if (vA + 16 + lk + 4 * v < A.v_end) Hrow1[v][r0 + li] = acc1[v];
+            }
+        }
+    }
+}
 
 template <int VPW, int NB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
@@ -886,13 +952,14 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     // every wave pulls its own VPW voxels and walks the flip angles alone, reading D, D^T and B through L1/L2 -- no barrier,
     // so no wave waits for the slowest solve of a tile (a tile kernel with D and B staged in LDS per flip angle spent 48 % of
     // its wave time in its two barriers per flip angle; removed in round 3).
-    const int64_t ntiles = (A.nvox + VPW - 1) / VPW;
+    const int64_t ntiles = (A.v_end - A.v0 + VPW - 1) / VPW;     // this pass: voxels [A.v0, A.v_end)
+    const int Mh = A.nfa * n;
     for (int64_t round = 0; round <= ntiles; ++round) {
         int t32 = 0;
         if (lane == 0) t32 = atomicAdd(A.queue, 1);
         const int64_t tile = __builtin_amdgcn_readfirstlane(t32);
         if (tile >= ntiles) break;
-        const int64_t v0 = tile * VPW;
+        const int64_t v0 = A.v0 + tile * VPW;
         double b[VPW], best_r[VPW], best_km[VPW];
         int best_fa[VPW];
         bool act[VPW];
@@ -906,7 +973,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             MET2_CYC_INIT(st[vv]);
             nnls_reset<NB>(st[vv]);
             const int64_t v = v0 + vv;
-            const bool in = v < A.nvox;
+            const bool in = v < A.v_end;
             b[vv] = (in && lane < m) ? A.data[v * A.vs + lane * A.es] : 0.0;
             double sum = wave_sum(b[vv]);
             bool mk = in && (A.mask ? (A.mask[v] != 0) : true);
@@ -922,7 +989,15 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #ifdef MET2_CYCSTATS
             const unsigned long long cv0 = __builtin_readcyclecounter();
 #endif
-            {                                  // rows of D come from L2: load each once for all the wave's voxels
+            if (A.H) {                         // h of this flip angle from the batched MFMA contraction: one contiguous row per voxel
+#pragma unroll
+                for (int vv = 0; vv < VPW; ++vv) {
+                    const int64_t vr = min(v0 + vv, A.v_end - 1) - A.v0;
+                    const double *hrow = A.H + (size_t)vr * Mh + (size_t)fa * n;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) { const int j = lane + 64 * bb; const double hv = hrow[min(j, n - 1)]; st[vv].h[bb] = (j < n) ? hv : 0.0; }
+                }
+            } else {                           // rows of D come from L2: load each once for all the wave's voxels
                 double hh[VPW][NB];
                 project_multi<NB, VPW>(S, b, lane, hh);
 #pragma unroll
@@ -955,11 +1030,11 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #pragma unroll
         for (int vv = 0; vv < VPW; ++vv) {
             const int64_t v = v0 + vv;
-            if (v < A.nvox && lane == 0) {
+            if (v < A.v_end && lane == 0) {
                 A.fa_index[v] = act[vv] ? (double)best_fa[vv] : 0.0;
                 if (A.km) A.km[v] = act[vv] ? best_km[vv] : 0.0;
             }
-            if (v < A.nvox && A.resid && !act[vv]) for (int f = lane; f < A.nfa; f += 64) A.resid[(size_t)v * A.nfa + f] = 0.0;
+            if (v < A.v_end && A.resid && !act[vv]) for (int f = lane; f < A.nfa; f += 64) A.resid[(size_t)v * A.nfa + f] = 0.0;
         }
     }
 }
@@ -1385,6 +1460,7 @@ struct met2_plan {
     bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
     bool seeds_ok = false;                                // B + lambda K is positive definite at the seed lambdas (checked on the host for
                                                           // flip angle 0): only then is the seeded start the cold start's solution
+    double *dH = nullptr; int64_t cap_h = 0;              // FA walk: h of every flip angle for one pass of voxels (fa_project_kernel), grown on demand
     double *dBtab = nullptr; int btab_stride = 0;         // BayesReg factor tables [nfa][MET2_BAYES_TABLE][btab_stride] (built with the seeds)
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
     int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
@@ -1886,7 +1962,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab};
+    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -2279,19 +2355,49 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
         g.lds = (int)(sizeof(double) * (size_t)g.wave_doubles * fa_waves + 64);
     }
     SortBufs sb = sort_bufs(p);
-    HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
     FaArgs A;
     A.n = p->n_t2; A.m = p->n_te; A.nfa = p->n_fa; A.kmax = g.kmax; A.waves = g.waves; A.wave_doubles = g.wave_doubles;
     A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Kd = p->dKd; A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.mask = mask; A.fa_index = fa_index; A.km = km; A.resid = resid;
     A.queue = sb.queue; A.nvox = nvox;
+    // h = D_fa^T b of all flip angles by one MFMA GEMM per pass of voxels (fa_project_kernel) when the plan has more than a handful
+    // of flip angles; the pass size bounds the scratch (8 nfa n bytes per voxel: 87 KB at 91 x 120)
+    const int64_t Mh = (int64_t)p->n_fa * p->n_t2;
+    const bool gemm = p->n_fa >= 8 && tuning_env("MET2_FA_GEMM", 0, 1, 1) != 0;
+    int64_t pass = nvox;
+    if (gemm) {
+        const int64_t budget = (int64_t)6 << 30;                                   // bytes of scratch
+        pass = std::max<int64_t>(32, std::min<int64_t>(nvox, (budget / (8 * Mh)) & ~(int64_t)31));
+        if (p->cap_h < pass * Mh) {
+            if (p->dH) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(p->dH)); p->dH = nullptr; p->cap_h = 0; }
+            HIPCHK(hipMalloc(&p->dH, sizeof(double) * (size_t)(pass * Mh)));
+            p->cap_h = pass * Mh;
+        }
+    }
     HIPCHK(hipEventRecord(p->ev0, s));
 #define MET2_FA_LAUNCH(VPW, NB, WAVES)                                                                                   \
     do {                                                                                                                \
         HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
         hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES>), dim3(g.grid), dim3(g.block), g.lds, s, A);                       \
     } while (0)
-    if (g.nb == 1) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16); else MET2_FA_LAUNCH(4, 1, 8); }
-    else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16); else MET2_FA_LAUNCH(2, 2, 8); }   // two voxels per wave at two bins per lane: same 57 ms (measured)
+    for (int64_t v0 = 0; v0 < nvox; v0 += pass) {
+        A.v0 = v0; A.v_end = std::min<int64_t>(nvox, v0 + pass); A.H = nullptr;
+        HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
+        if (gemm) {
+            FaGemmArgs G;
+            G.n = p->n_t2; G.m = p->n_te; G.nfa = p->n_fa; G.Dtfa = p->dDt; G.data = data; G.vs = voxel_stride; G.es = echo_stride; G.H = p->dH;
+            G.v0 = v0; G.v_end = A.v_end;
+            const int64_t waves = (A.v_end - v0 + 31) / 32;
+            const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+            const int ks = (p->n_te + 3) / 4;
+            if (ks <= 8)       hipLaunchKernelGGL(fa_project_kernel<8>, grid, block, 0, s, G);
+            else if (ks <= 12) hipLaunchKernelGGL(fa_project_kernel<12>, grid, block, 0, s, G);
+            else               hipLaunchKernelGGL(fa_project_kernel<16>, grid, block, 0, s, G);
+            HIPCHK(hipGetLastError());
+            A.H = p->dH;
+        }
+        if (g.nb == 1) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16); else MET2_FA_LAUNCH(4, 1, 8); }
+        else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16); else MET2_FA_LAUNCH(2, 2, 8); }   // two voxels per wave at two bins per lane: same 57 ms (measured)
+    }
 #undef MET2_FA_LAUNCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev1, s));
