@@ -5,7 +5,7 @@ For every set of defines: rebuild the X2-only library, one plain bench run (kern
 and wait counters of the dominant fit_kernel dispatch).  Prints one line per build."""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CTRS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_LDS_IDX_ACTIVE"]
+CTRS = os.environ["CTRS"].split() if os.environ.get("CTRS") else ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_LDS_IDX_ACTIVE"]
 bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
 for defs in sys.argv[1:]:
     env = dict(os.environ, MET2_BUILD_DEFINES="-DMET2_ONLY=2 " + defs, TMPDIR="/tmp")
@@ -29,6 +29,9 @@ for defs in sys.argv[1:]:
             if int(r["Dispatch_Id"]) == best:
                 tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     nv = line["config"]["fitted_voxels_per_gpu"]
+    if os.environ.get("CTRS"):
+        print("DEFS [%s] kernel_ms %.2f | " % (defs, line["roofline"]["kernel_ms"]) + " ".join("%s=%.4g" % (k, v) for k, v in sorted(tot.items())), flush=True)
+        continue
     print("DEFS [%s] kernel_ms %.2f | per voxel: VALU %.0f SALU %.0f LDS %.0f | ACTIVE_VALU/WAVE_CYC %.3f WAIT_INST %.3f WAIT_ANY %.3f LDS_ACTIVE(quad-cyc/voxel) %.0f" % (
         defs, line["roofline"]["kernel_ms"], tot.get("SQ_INSTS_VALU", 0) / nv, tot.get("SQ_INSTS_SALU", 0) / nv, tot.get("SQ_INSTS_LDS", 0) / nv,
         tot.get("SQ_ACTIVE_INST_VALU", 0) / max(tot.get("SQ_WAVE_CYCLES", 1), 1), tot.get("SQ_WAIT_INST_ANY", 0) / max(tot.get("SQ_WAVE_CYCLES", 1), 1),
