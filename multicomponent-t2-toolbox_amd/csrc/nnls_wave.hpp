@@ -32,7 +32,7 @@ namespace met2 {
 #define MET2_DOUBLE 0
 #endif
 #ifndef MET2_REORDER
-#define MET2_REORDER 0        // 1: warm starts re-order the passive set by descending x (reorder_by_x below; measured neutral, see there)
+#define MET2_REORDER 2        // bins per lane from which warm starts re-order the passive set by descending x (reorder_by_x below); 1: always, 3: never
 #endif
 
 #ifdef MET2_LOOPSTATS
@@ -1098,9 +1098,11 @@ __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &
 // whose coefficient is already small: measured on the reference's recipe (consecutive Brent abscissae, 150 voxels) the leaving bin is
 // the smallest-x bin of the set in 42 % of the removals and among the three smallest in 83 %, so with the smallest coefficients LAST
 // the chains have one or two links where the entering order (largest dual first) gave ~15.
-// MEASURED (round 3, configs[1]): the removals' wave cycles fell 6x (5.4 k -> 0.9 k per Brent evaluation) but the kernel did not
-// get faster (147.5 vs 147.7 ms) and its vector-instruction count barely moved (60.7 k -> 60.5 k per voxel): the chains were long in
-// latency (an LDS round trip per link), not in instructions, and the kernel is bound by vector-instruction issue.  Off by default.
+// MEASURED (round 3): at one bin per lane (configs[1]) the removals' wave cycles fell 6x (5.4 k -> 0.9 k per Brent evaluation) but
+// the kernel did not get faster (147.5 vs 147.7 ms) and its vector-instruction count barely moved (60.7 k -> 60.5 k per voxel): the
+// chains were long in latency (an LDS round trip per link), not in instructions, and that kernel is bound by vector-instruction
+// issue -- off there.  At two bins per lane (k ~ 40, every link two registers wide) it pays: X2/L2 at 48 x 120 32.1 -> 30.2 ms
+// per 32 768 voxels (+7 %), the GCV kernel of configs[4] +1.4 %; L-curve at 32 x 60 +0.4 %.  On from MET2_REORDER bins per lane.
 // Keys: the bit pattern of x (non-negative doubles order like unsigned integers) with its low 7 bits replaced by 127 - bin: all
 // different, so the ranks form a permutation whatever the data (any pivot order is valid; only the cost depends on it).  The new
 // position -> bin table goes through the wave's factor region, which the re-factorisation overwrites next.
@@ -1157,7 +1159,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     const int kold = st.k;
     if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
-    if (MET2_REORDER && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
+    if (NB >= MET2_REORDER && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
     if (!refactor<NB>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
         int ordold[NB];

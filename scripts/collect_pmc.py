@@ -53,7 +53,7 @@ def find(d, suffix):
     return hits[0]
 
 
-def counters(d, kernel_substr, steps=2):
+def counters(d, kernel_substr, steps=2, sum_step=False):
     """{counter: value} of the dominant dispatch of the last step of the kernel whose name contains kernel_substr.  A method
     with a clean-up pass launches the same kernel symbol twice per step (first pass, then the few voxels that hit the capacity):
     of the last step's dispatches the one with the largest first counter is reported."""
@@ -71,7 +71,7 @@ def counters(d, kernel_substr, steps=2):
             best, best_val = i, v
     out = {}
     for r in rows:
-        if int(r["Dispatch_Id"]) == best:
+        if (int(r["Dispatch_Id"]) in last_step) if sum_step else (int(r["Dispatch_Id"]) == best):
             out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     return out, rows[0]["Kernel_Name"]
 
@@ -82,9 +82,10 @@ def main():
     ap.add_argument("--key", required=True, help="entry name in pmc_counters.json: config<N> for a BASELINE config at full size")
     ap.add_argument("--kernel", default="fit_kernel", help="substring of the kernel to report (default: the fit kernel)")
     ap.add_argument("--timeout", type=int, default=900)
+    ap.add_argument("--sum", action="store_true", help="sum the counters over ALL dispatches of the kernel in the last step (a kernel launched once per pass of voxels)")
     ap.add_argument("bench", nargs=argparse.REMAINDER)
     a = ap.parse_args()
-    bench_args = [x for x in a.bench if x != "--"] + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    bench_args = [x for x in a.bench if x != "--"] + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
     out = os.path.join(ROOT, "gpurun_out")
     work = os.path.join(out, "%s_%s_prof" % (a.tag, a.key))
     os.makedirs(work, exist_ok=True)
@@ -107,7 +108,7 @@ def main():
     for name, ctrs in groups:
         try:
             dd = run_prof(work, name, ["--kernel-trace", "--pmc"] + ctrs, bench_args, a.timeout)
-            c, kn = counters(dd, sub)
+            c, kn = counters(dd, sub, sum_step=a.sum)
             allc.update(c)
         except SystemExit as e:
             print("pass %s skipped: %s" % (name, e), file=sys.stderr)

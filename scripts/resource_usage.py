@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static per-kernel summaries of the current sources (runs here, no GPU):
-    python3 scripts/resource_usage.py        -> profiles/r02_kernel_resource_usage.csv, profiles/r02_mfma_disassembly.txt
+    python3 scripts/resource_usage.py        -> profiles/r03_kernel_resource_usage.csv, profiles/r03_mfma_disassembly.txt
 Registers, spills and occupancy from hipcc -Rpass-analysis=kernel-resource-usage; v_mfma_f64_16x16x4 counts from the -S output."""
 import os, re, subprocess, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ def main():
     p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-disable-machine-licm", "-S", "--cuda-device-only",
                         "-Rpass-analysis=kernel-resource-usage", "-o", asm, SRC], capture_output=True, text=True)
     blocks = re.split(r"remark: Function Name: ", p.stderr)[1:]
-    with open(os.path.join(ROOT, "profiles", "r02_kernel_resource_usage.csv"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r03_kernel_resource_usage.csv"), "w") as f:
         f.write("# hipcc --offload-arch=gfx950 -O3 -mllvm -disable-machine-licm -Rpass-analysis=kernel-resource-usage (scripts/resource_usage.py), sources of the current evidence\n")
         f.write("# kernel, VGPRs, AGPRs, SGPRs, SGPR spills, VGPR spills, scratch B/lane, occupancy waves/SIMD\n")
         for b in blocks:
@@ -34,7 +34,7 @@ def main():
         if hits:
             rows.append((demangle(m.group(1)), len(hits)))
             sample = sample or hits[:4]
-    with open(os.path.join(ROOT, "profiles", "r02_mfma_disassembly.txt"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r03_mfma_disassembly.txt"), "w") as f:
         f.write("# hipcc --offload-arch=gfx950 -O3 -S: static count of v_mfma_f64_16x16x4_f64 instructions per kernel (scripts/resource_usage.py)\n")
         f.write("# GCV: the Gram contraction M = E E^T of objectives.hpp:gcv_trace_direct; BayesReg: the trailing updates of objectives.hpp:chol_full;\n")
         f.write("# every method at two bins per lane: the trailing updates of nnls_wave.hpp:refactor_blocked (four per inlined copy)\n")
