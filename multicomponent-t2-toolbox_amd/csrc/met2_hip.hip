@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                                 st.x[bb] = keep_x[q][bb]; st.pos[bb] = (keep_p[q][bb] & 0x1ff) - 1; st.ord[bb] = keep_p[q][bb] >> 9;
                                 st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
                             }
-                            st.k = kk; st.hist = 0;              // (the trend on record belongs to the end of the sweep, not to this state)
+                            st.k = kk;
                         }
                 }
                 nnls_solve_warm<NB>(S, bd, st, regv, true, lane);

@@ -31,9 +31,6 @@ namespace met2 {
 #ifndef MET2_DOUBLE
 #define MET2_DOUBLE 0
 #endif
-#ifndef MET2_PREDICT
-#define MET2_PREDICT 1        // 1: warm solves drop the bins a log-lambda extrapolation sends below zero before re-factorising (predict_and_drop)
-#endif
 #ifndef MET2_REORDER
 #define MET2_REORDER 2        // bins per lane from which warm starts re-order the passive set by descending x (reorder_by_x below); 1: always, 3: never
 #endif
@@ -99,9 +96,6 @@ struct NnlsState {
     int k;             // |P|                (uniform)
     u64 P[NB];         // passive-set mask   (uniform)
     int itmax_hit;     // uniform flags: bit0 iteration cap reached, bit1 passive set hit the capacity kmax < n
-    double xprev[NB];  // iterate of the warm solve before the last one (bin-indexed), for predict_and_drop()
-    double ll_cur, ll_prev;   // log lambda of the last two warm solves (uniform)
-    int hist;          // warm solves on record: 0, 1 or 2 (uniform)
 #ifdef MET2_CYCSTATS
     unsigned long long cyc[16];
 #endif
@@ -675,8 +669,8 @@ template <int NB>
 __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { st.x[b] = 0.0; st.y[b] = 0.0; st.rinv[b] = 0.0; st.ord[b] = 0; st.pos[b] = -1; st.P[b] = 0ull; st.xprev[b] = 0.0; }
-    st.k = 0; st.hist = 0; st.ll_cur = 0.0; st.ll_prev = 0.0;
+    for (int b = 0; b < NB; ++b) { st.x[b] = 0.0; st.y[b] = 0.0; st.rinv[b] = 0.0; st.ord[b] = 0; st.pos[b] = -1; st.P[b] = 0ull; }
+    st.k = 0;
 }
 
 // Row-by-row form of the refactorisation: every row sums over ALL rows above it.  Used at one bin per lane (k <= 64), where it
@@ -1155,79 +1149,6 @@ __device__ __forceinline__ void reorder_by_x(const WaveShared &S, NnlsState<NB> 
     __builtin_amdgcn_wave_barrier();
 }
 
-// Which bins will leave at the next lambda?  Along a lambda search the coefficients move smoothly in log lambda, and the bins that leave
-// are the ones already heading for zero: extrapolating each coefficient linearly in log lambda from the last two solves,
-// x_pred = x + rho (x - x_prev), rho = (ln lam_new - ln lam) / (ln lam - ln lam_prev), and dropping the bins with x_pred <= 0 BEFORE
-// the re-factorisation finds 80 % of the bins that leave (measured on the reference's recipe along Brent's abscissae: of 1.03 leaving
-// per step 0.82 are predicted, 0.18 per step are dropped wrongly and come back through the dual) -- each one a secondary-loop pass
-// (back substitution, ratio test, plane-rotation chain) that no longer runs.  Any x >= 0 supported on the passive set is a feasible
-// start and the problem has one minimiser: the result is the cold start's up to rounding whatever the prediction does.
-template <int NB>
-__device__ __forceinline__ void predict_and_drop(const WaveShared &S, NnlsState<NB> &st, double lam, int lane)
-{
-    const double ll_new = log(lam);
-    const double den = st.ll_cur - st.ll_prev;
-    double rho = (ll_new - st.ll_cur) / den;
-    if (!(fabs(den) > 1e-12) || !(fabs(rho) <= 2.0)) return;             // no trend to speak of, or too far to extrapolate
-    bool leave[NB];
-    bool any = false;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const bool in = (st.P[b] >> lane) & 1ull;
-        leave[b] = in && !(fma(rho, st.x[b] - st.xprev[b], st.x[b]) > 0.0);
-        any = any || (ballot(leave[b]) != 0ull);
-    }
-    if (!any) return;
-    // compact the pivot order: the bins that stay keep their relative order (new position = number of staying positions below)
-    int lvi[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) lvi[b] = leave[b] ? 1 : 0;
-    u64 stay[NB];                                                        // by POSITION
-    const int k = st.k;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int pl = lane + 64 * b;
-        const int gone = gatherN_i<NB>(lvi, st.ord[b]);                  // does the bin at this position leave?
-        stay[b] = ballot(pl < k && gone == 0);
-    }
-    int *tab = (int *)S.R;                                               // new position -> bin (the factor is rebuilt next)
-    int knew = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) knew += __popcll(stay[b]);
-    int below = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int pl = lane + 64 * b;
-        const bool keep = (stay[b] >> lane) & 1ull;
-        const int np = below + __popcll(stay[b] & ((1ull << lane) - 1ull));
-        if (keep) tab[np] = st.ord[b];
-        if (pl >= knew && pl < 64 * NB) tab[pl] = 0;                      // positions behind the set name a valid bin
-        below += __popcll(stay[b]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int b = 0; b < NB; ++b) st.ord[b] = tab[lane + 64 * b];
-    __builtin_amdgcn_wave_barrier();
-    // bin-indexed: new positions, passive mask, x of the dropped bins
-    int posn[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) posn[b] = -1;
-    // position p (lane p) knows its bin; scatter p to the bin's lane through the table
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; if (pl < knew) tab[64 * NB + st.ord[b]] = pl; }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const bool in = ((st.P[b] >> lane) & 1ull) && !leave[b];
-        const int pv = tab[64 * NB + lane + 64 * b];
-        st.pos[b] = in ? pv : -1;
-        st.x[b] = leave[b] ? 0.0 : st.x[b];
-        st.P[b] = ballot(in);
-    }
-    __builtin_amdgcn_wave_barrier();
-    st.k = knew;
-}
-
 // Warm start: keep the previous solution's passive set and x (a feasible point for any lambda),
 // rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
 // strictly convex problem does not depend on the starting point, so this returns the same x as the
@@ -1235,20 +1156,9 @@ __device__ __forceinline__ void predict_and_drop(const WaveShared &S, NnlsState<
 template <int NB>
 __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
-    int kold = st.k;
+    const int kold = st.k;
     if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
-    if (MET2_PREDICT && lam > 0.0) {
-        double xold[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) xold[b] = st.x[b];
-        if (st.hist >= 2 && kold >= 4 && S.rcap >= 64 * NB + 2) predict_and_drop<NB>(S, st, lam, lane);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) st.xprev[b] = xold[b];               // the iterate this solve starts from becomes "the one before"
-        st.ll_prev = st.ll_cur; st.ll_cur = log(lam); st.hist = st.hist < 2 ? st.hist + 1 : 2;
-        if (st.k == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
-        kold = st.k;
-    }
     if (NB >= MET2_REORDER && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
     if (!refactor<NB>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
