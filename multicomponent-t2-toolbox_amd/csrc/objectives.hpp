@@ -335,17 +335,19 @@ __host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = 
 // instead of divisions keep the dependent chain at two operations per row).  Two registers alternate as p_{j-1} / p_{j-2}, a sign
 // change is one xor of the high words, and the pair is rescaled by a power of two every eight rows (per row the minors grow by at
 // most the Gershgorin bound and shrink by no more than ~1e-16 of it).
-// Three shifts per lane at once: the three chains are independent (they hide each other's fp64 latency) and share the
-// row broadcasts.
-__device__ __forceinline__ void sturm_count3(double dreg, double e2reg, int n, const double (&x)[3], int (&out)[3])
+// C shifts per lane at once: the chains are independent (they hide each other's fp64 latency) and share the row broadcasts.
+template <int C>
+__device__ __forceinline__ void sturm_count(double dreg, double e2reg, int n, const double (&x)[C], int (&out)[C])
 {
     // lane j holds (d_j, e_{j-1}^2); a row's pair reaches the scalar registers through v_readlane (no memory round trip)
-    double pa[3] = {1.0, 1.0, 1.0}, pb[3] = {0.0, 0.0, 0.0};     // p_{j-1}, p_{j-2}; after a row the roles swap
-    unsigned cnt[3] = {0u, 0u, 0u};
+    double pa[C], pb[C];                                         // p_{j-1}, p_{j-2}; after a row the roles swap
+    unsigned cnt[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { pa[c] = 1.0; pb[c] = 0.0; cnt[c] = 0u; }
     auto row2 = [&](int j) {                                     // rows j (-> pb) and j + 1 (-> pa)
         const double d0 = bcast(dreg, j), f0 = bcast(e2reg, j), d1 = bcast(dreg, j + 1), f1 = bcast(e2reg, j + 1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < C; ++c) {
             pb[c] = fma(d0 - x[c], pa[c], -(f0 * pb[c]));
             cnt[c] += ((unsigned)(__double2hiint(pb[c]) ^ __double2hiint(pa[c]))) >> 31;
             pa[c] = fma(d1 - x[c], pb[c], -(f1 * pa[c]));
@@ -356,7 +358,7 @@ __device__ __forceinline__ void sturm_count3(double dreg, double e2reg, int n, c
     for (; j + 8 <= n; j += 8) {
         row2(j); row2(j + 2); row2(j + 4); row2(j + 6);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < C; ++c) {
             const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(pa[c]), fabs(pb[c])));
             pa[c] = ldexp(pa[c], -ex); pb[c] = ldexp(pb[c], -ex);
         }
@@ -365,13 +367,13 @@ __device__ __forceinline__ void sturm_count3(double dreg, double e2reg, int n, c
     if (j < n) {
         const double d0 = bcast(dreg, j), f0 = bcast(e2reg, j);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < C; ++c) {
             pb[c] = fma(d0 - x[c], pa[c], -(f0 * pb[c]));
             cnt[c] += ((unsigned)(__double2hiint(pb[c]) ^ __double2hiint(pa[c]))) >> 31;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = (int)cnt[c];
+    for (int c = 0; c < C; ++c) out[c] = (int)cnt[c];
 }
 
 // The tridiagonal form of M for a support, at c = 1, kept from one Brent evaluation to the next: M = [[c k, sqrt(c) b^T],
@@ -550,22 +552,83 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     const double bound = fmax(wave_max((lane < n) ? fabs(dj) + fabs(ej) + fabs(eprev) : 0.0), 1e-300);
     __builtin_amdgcn_wave_barrier();
     MET2_GCV_LAP(9);
-    // ---- 3. bisection on the bit patterns: lane i -> the (i+1)-th largest eigenvalue
+    // ---- 3. the eigenvalues that survive the cut, by multisection on the bit patterns.
+    // Only eigenvalues above eps k mu_max enter the trace (np.linalg.lstsq drops the rest) -- 7 to 16 of the 33 / 49 -- so the lanes are
+    // spent on those instead of one lane per eigenvalue:
+    //   A. the largest eigenvalue: all 64 lanes x 2 shifts = a 129-section per Sturm pass (7 bits), 4 passes;
+    //   B. r = number of eigenvalues above the cut: one pass;
+    //   C. the r largest: a group of G = 64 / 16 = 4 lanes x 2 shifts per eigenvalue = a 9-section per pass (3.17 bits), 9 passes;
+    //      more than 16 survivors (not seen on the reference's recipe): the one-lane-per-eigenvalue quaternary search of round 2.
+    // 14 passes of 2 chains instead of 14 of 3, and the eigenvalues under the cut are never refined.
     // the Gershgorin bound is at most sqrt(n) mu_max, so bound * 1e-18 lies below any cut eps k mu_max
-    unsigned long long lo = (unsigned long long)__double_as_longlong(bound * 1e-18);
-    unsigned long long hi = (unsigned long long)__double_as_longlong(bound * 1.0000001);
-    const int want = n - lane;                // eigenvalue number (1-based, ascending) this lane is after
-    for (int step = 0; step < 14; ++step) {   // two bits per step: 60 octaves -> 3 steps for the exponent, 11 for 22 bits of relative position (2.4e-7)
-        const unsigned long long q = (hi - lo) >> 2;
-        const unsigned long long m1 = lo + q, m2 = lo + 2 * q, m3 = lo + 3 * q;
-        const double xs[3] = {__longlong_as_double((long long)m1), __longlong_as_double((long long)m2), __longlong_as_double((long long)m3)};
-        int c[3];
-        sturm_count3(dj, e2prev, n, xs, c);
-        const bool u1 = c[0] >= want, u2 = c[1] >= want, u3 = c[2] >= want;       // at least `want` eigenvalues below the shift
-        hi = u1 ? m1 : (u2 ? m2 : (u3 ? m3 : hi));
-        lo = u1 ? lo : (u2 ? m1 : (u3 ? m2 : m3));
+    double mu;
+    int r_keep;
+    {
+        unsigned long long lo = (unsigned long long)__double_as_longlong(bound * 1e-18);
+        unsigned long long hi = (unsigned long long)__double_as_longlong(bound * 1.0000001);
+        for (int step = 0; step < 4; ++step) {                       // A: 129^4 = 2.8e8 > 2^28 (60 octaves -> 2.4e-7 relative)
+            const unsigned long long q = (hi - lo) / 129ull;
+            const unsigned long long m1 = lo + (unsigned long long)(2 * lane + 1) * q, m2 = m1 + q;
+            const double xs[2] = {__longlong_as_double((long long)m1), __longlong_as_double((long long)m2)};
+            int c[2];
+            sturm_count<2>(dj, e2prev, n, xs, c);
+            const u64 a1 = ballot(c[0] >= n), a2 = ballot(c[1] >= n);                // all n eigenvalues below the shift
+            // shifts in ascending order: lane 0 (m1, m2), lane 1, ...: the first shift above the largest eigenvalue
+            const int f1 = a1 ? first_lane(a1) : 64, f2 = a2 ? first_lane(a2) : 64;
+            const int first = min(2 * f1, 2 * f2 + 1);                              // index 0 .. 127 into the shifts, 128: none
+            const unsigned long long nhi = first < 128 ? lo + (unsigned long long)(first + 1) * q : hi;
+            const unsigned long long nlo = first > 0 ? lo + (unsigned long long)first * q : lo;
+            hi = nhi; lo = nlo;
+        }
+        const double mumax_ = __longlong_as_double((long long)hi);
+        const double cut_ = 2.220446049250313e-16 * (double)k * mumax_;
+        {                                                                            // B
+            const double xs[1] = {cut_};
+            int c[1];
+            sturm_count<1>(dj, e2prev, n, xs, c);
+            r_keep = n - c[0];
+        }
+        if (r_keep <= 16) {                                                          // C
+            const int e = lane >> 2, sidx = lane & 3;
+            const int want = n - e;                                                  // the (e+1)-th largest: at least `want` eigenvalues below the shift
+            unsigned long long glo = (unsigned long long)__double_as_longlong(cut_ * 0.9999999);
+            unsigned long long ghi = hi;
+            for (int step = 0; step < 9; ++step) {                                   // 9^9 = 3.9e8 > 2^28
+                const unsigned long long q = (ghi - glo) / 9ull;
+                const unsigned long long m1 = glo + (unsigned long long)(2 * sidx + 1) * q, m2 = m1 + q;
+                const double xs[2] = {__longlong_as_double((long long)m1), __longlong_as_double((long long)m2)};
+                int c[2];
+                sturm_count<2>(dj, e2prev, n, xs, c);
+                const u64 a1 = ballot(c[0] >= want), a2 = ballot(c[1] >= want);
+                const unsigned q1 = (unsigned)(a1 >> (lane & ~3)) & 15u, q2 = (unsigned)(a2 >> (lane & ~3)) & 15u;   // the group's four lanes
+                const int f1 = q1 ? __builtin_ctz(q1) : 4, f2 = q2 ? __builtin_ctz(q2) : 4;
+                const int first = min(2 * f1, 2 * f2 + 1);                          // 0 .. 7, 8: none
+                const unsigned long long nhi = first < 8 ? glo + (unsigned long long)(first + 1) * q : ghi;
+                const unsigned long long nlo = first > 0 ? glo + (unsigned long long)first * q : glo;
+                ghi = nhi; glo = nlo;
+            }
+            // lane i < r takes eigenvalue i (its group's result sits in lanes 4 i .. 4 i + 3)
+            const double mug = __longlong_as_double((long long)ghi);
+            mu = gather(mug, (4 * lane) & 63);
+            mu = (lane == 0) ? mumax_ : mu;
+            mu = (lane < r_keep) ? mu : 0.0;                                         // under the cut: dropped below (mu > cut fails)
+        } else {
+            unsigned long long lo2 = (unsigned long long)__double_as_longlong(bound * 1e-18);
+            unsigned long long hi2 = (unsigned long long)__double_as_longlong(bound * 1.0000001);
+            const int want = n - lane;                                               // eigenvalue number (1-based, ascending) this lane is after
+            for (int step = 0; step < 14; ++step) {
+                const unsigned long long q = (hi2 - lo2) >> 2;
+                const unsigned long long m1 = lo2 + q, m2 = lo2 + 2 * q, m3 = lo2 + 3 * q;
+                const double xs[3] = {__longlong_as_double((long long)m1), __longlong_as_double((long long)m2), __longlong_as_double((long long)m3)};
+                int c[3];
+                sturm_count<3>(dj, e2prev, n, xs, c);
+                const bool u1 = c[0] >= want, u2 = c[1] >= want, u3 = c[2] >= want;
+                hi2 = u1 ? m1 : (u2 ? m2 : (u3 ? m3 : hi2));
+                lo2 = u1 ? lo2 : (u2 ? m1 : (u3 ? m2 : m3));
+            }
+            mu = __longlong_as_double((long long)hi2);
+        }
     }
-    const double mu = __longlong_as_double((long long)hi);
     MET2_GCV_LAP(10);
     // ---- 4. squared first eigenvector components: 1 / r_0'(mu)
     const double pivmin = 1e-290;

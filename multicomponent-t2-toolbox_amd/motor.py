@@ -472,7 +472,7 @@ def recon_met2_rois(data, rois, fa_index, Dic_3D, T2s, Laplac, factor=1.01, myel
     Returns dict(labels, count, fsol [nROI, nT2] normalised to sum 1 like the reference, MWF, IEWF, FWF, T2_M, T2_IE, TWC,
     reg_opt, k_est, mean_signal)."""
     from .plan import voxel_layout, _ptr
-    src = plan if plan is not None else plan_for(Dic_3D)
+    src = plan if plan is not None else plan_for(Dic_3D, device=device)
     dev = src.device
     dd = torch.as_tensor(data, dtype=torch.float64, device=dev)
     nt = dd.shape[-1]
