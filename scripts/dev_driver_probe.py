@@ -14,11 +14,14 @@ mask = np.ones(dims, dtype=np.int64)
 TE = 10.0 * np.arange(1, 33)
 fa_known = np.full(dims, 60.0)
 for fa_method, smooth, fa_idx in (("brute-force", "no", fa_known), ("spline", "yes", None), ("spline", "no", None), ("brute-force", "no", None)):
-    for rep in range(3):
+    best = None
+    for rep in range(4):
         res = None                                   # (frees the previous call's pinned outputs: the caching host allocator hands them out again)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         res = motor.recon_met2_arrays(data, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, FA_smooth=smooth, fa_index=fa_idx)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if (best is None or rep == 1) else min(best, dt)          # the first call of a kind pins its buffers: best of the later three
+    dt = best
     print(json.dumps({"driver": "recon_met2_arrays", "dims": dims, "FA_method": "given (single FA)" if fa_idx is not None else fa_method, "FA_smooth": smooth,
                       "path": "one-shot (whole volume on the device)" if smooth == "yes" else "chunked host pipeline", "seconds": dt,
                       "voxels_per_s": nvox / dt, "MWF_mean": float(res["MWF"].mean())}))
