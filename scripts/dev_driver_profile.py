@@ -1,0 +1,27 @@
+"""Where does recon_met2_arrays spend its wall time?  cProfile of the third call on a configs[1]-sized volume with the flip angle given
+(the fit alone: no FA step), pageable numpy input.  Run on the GPU box."""
+import cProfile, importlib, io, pstats, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+motor = importlib.import_module("multicomponent-t2-toolbox_amd.motor")
+synth = importlib.import_module("multicomponent-t2-toolbox_amd.synth")
+dims = (128, 128, 64)
+nvox = int(np.prod(dims))
+data, _, _ = synth.make_voxels(nvox, nte=32, seed=9, fa_deg=150.0, device="cuda")
+data = data.cpu().numpy().reshape(dims + (32,))
+mask = np.ones(dims, dtype=np.int64)
+TE = 10.0 * np.arange(1, 33)
+fa_known = np.full(dims, 60.0)
+for rep in range(3):
+    res = None
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    if rep == 2:
+        pr = cProfile.Profile(); pr.enable()
+    res = motor.recon_met2_arrays(data, mask, TE, 3000.0, "X2", "L2", "brute-force", 40.0, fa_index=fa_known)
+    torch.cuda.synchronize()
+    if rep == 2:
+        pr.disable()
+    print("call %d: %.3f s" % (rep, time.perf_counter() - t0), flush=True)
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
+print(s.getvalue())
