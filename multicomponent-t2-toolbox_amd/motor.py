@@ -174,13 +174,16 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
             k = c & 1
             lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
             n = hi - lo
-            if c >= 2:
-                ev_fit[k].synchronize()            # the fit of chunk c - 2 has read this slot (its H2D finished long before)
             h = src[:, lo:hi] if echo_major else src[lo:hi]
             if stage is not None:
+                if c >= 2:
+                    ev_in[k].synchronize()          # the H2D of chunk c - 2 has left this staging buffer (it finished before that chunk's fit began)
                 cut(stage[k], n).copy_(h)           # pageable -> pinned (host memcpy, one segment per echo when echo-major)
                 h = cut(stage[k], n)
             with torch.cuda.stream(s_in):
+                if c >= 2:                          # the device slot is free once chunk c - 2 has been fitted and its outputs (fa_index) copied out:
+                    s_in.wait_event(ev_fit[k])      # waited for on the GPU, not by the host -- the host goes on staging while the GPU fits
+                    s_in.wait_event(ev_out[k])
                 cut(d_in[k], n).copy_(h, non_blocking=True)
                 if fa_h is not None:
                     d_fa[k][:n].copy_(fa_h[lo:hi], non_blocking=True)
@@ -195,8 +198,6 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
             k = c & 1
             lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
             n = hi - lo
-            if c + 1 < nch:
-                upload(c + 1)
             with torch.cuda.stream(s_fit):
                 s_fit.wait_event(ev_in[k])
                 if c >= 2:
@@ -236,6 +237,8 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                 for i in range(6):
                     res["maps"][i, lo:hi].copy_(maps_v[i], non_blocking=True)
                 ev_out[k].record(s_out)
+            if c + 1 < nch:
+                upload(c + 1)                       # staged and enqueued while the GPU works on chunk c
         with torch.cuda.stream(s_fit):
             plan.finish()
         s_out.synchronize()
