@@ -188,7 +188,7 @@ def plumbing_main(args, rank, world, mdist):
     return 0 if ok else 4
 
 
-def end_to_end(plan, pkg, method, data, brute, chunk_vox=131072, reps=2):
+def end_to_end(plan, pkg, method, data, brute, chunk_vox=262144, reps=3):
     """Region (iii) of SURVEY.md section 8d on this rank: the volume in PINNED host memory -> chunked H2D -> [FA estimation] -> fit ->
     D2H of fsol, Est_Signal, reg_param and the six maps into pinned host buffers, copies and kernels overlapped on two streams
     (motor.fit_host_pipeline, the pipeline recon_met2_arrays uses)."""
