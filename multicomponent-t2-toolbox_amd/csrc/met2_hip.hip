@@ -592,6 +592,9 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, kmax = A.kmax;
+    // one position slot while k <= 64 (nnls_wave.hpp: MET2_ONE_SLOT) in the two-bins-per-lane kernels that have the registers for a second
+    // code path: NNLS, T2SPARC, X2, L-curve (GCV at 255 VGPRs and BayesReg at 241 do not)
+    constexpr bool ONE = (NB == 2) && ((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE);
     const int tri = A.wave_doubles;
     double *sR = smem + (size_t)wave * tri;             // every wave's region starts 16-byte aligned
 
@@ -649,14 +652,14 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
 
             if (METHOD == MET2_NNLS) {
-                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+                nnls_solve<NB, ONE>(S, bd, st, 0.0, false, lane);
             } else if (METHOD == MET2_T2SPARC) {
-                if (have_seed) { seed_load<NB>(st, A.seed, seed_k, fa, lane); nnls_solve_warm<NB>(S, bd, st, A.t2sparc_lambda, true, lane); }
-                else nnls_solve<NB>(S, bd, st, A.t2sparc_lambda, true, lane);
+                if (have_seed) { seed_load<NB>(st, A.seed, seed_k, fa, lane); nnls_solve_warm<NB, ONE>(S, bd, st, A.t2sparc_lambda, true, lane); }
+                else nnls_solve<NB, ONE>(S, bd, st, A.t2sparc_lambda, true, lane);
                 regv = lamv = A.t2sparc_lambda;
             } else if (METHOD == MET2_X2) {
                 // algorithms.py:211-233
-                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+                nnls_solve<NB, ONE>(S, bd, st, 0.0, false, lane);
                 const double SSE = sse_of<NB>(S, st, b, lane);
                 const double target = A.x2_factor * SSE;
                 int flag;
@@ -678,7 +681,9 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                     canon = (evi == 0) ? gm_ * 10.0 : (evi == 1 ? canon + gm_ * (10.0 - canon) : (evi == 2 ? gm_ * 10.0 * (1.0 - gm_) : canon * (1.0 - gm_)));
                     const bool is_canon = fabs(x - canon) <= 1e-12 * canon;
 #endif
-                    nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    if (st.itmax_hit & 2) return 0.0;               // the passive set hit the pass's capacity: the voxel is solved again in the
+                                                                    // next pass, the rest of its Brent path here costs nothing
+                    nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
                     double SSEr = sse_of<NB>(S, st, b, lane);
 #ifdef MET2_CYCSTATS
                     if (lane == 0) {
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                     for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
                 }, 0.0, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                if (lam != last_x) {
+                if (lam != last_x && !(st.itmax_hit & 2)) {
                     int kk = 0;
 #pragma unroll
                     for (int bb = 0; bb < NB; ++bb) {
@@ -719,7 +724,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 int keep_p[NS][NB];
                 for (int i = 0; i < A.nlam; ++i) {
                     double lam = A.lam_grid[i];
-                    nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                    if (st.itmax_hit & 2) break;                    // capacity hit: solved again in the next pass
+                    nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
                     double sse = sse_of<NB>(S, st, b, lane);
                     double sn = seminorm2<NB>(bd, st.x, n, lane);
                     if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                             for (int bb = 0; bb < NB; ++bb) { keep_x[q][bb] = st.x[bb]; keep_p[q][bb] = (st.pos[bb] + 1) | (st.ord[bb] << 9); }
                         }
                 }
+                if (!(st.itmax_hit & 2)) {
                 int corner = select_corner_dev(le, ln, A.nlam, lane);
                 regv = lamv = A.lam_grid[corner];
                 {
@@ -752,7 +759,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                             st.k = kk;
                         }
                 }
-                nnls_solve_warm<NB>(S, bd, st, regv, true, lane);
+                nnls_solve_warm<NB, ONE>(S, bd, st, regv, true, lane);
+                }
             } else if (METHOD == MET2_BAYESREG) {
                 // bayesian_interpolation.py:84-105
                 nnls_solve<NB>(S, bd, st, 0.0, false, lane);
@@ -787,12 +795,13 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
+                    if (st.itmax_hit & 2) return 0.0;               // capacity hit: solved again in the next pass
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     return gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
                 }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
-                nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                if (!(st.itmax_hit & 2)) nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             }
             if (METHOD >= 10) {
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
                 if (!act[vv]) continue;
-                nnls_solve_warm<NB>(S, bd, st[vv], 0.0, false, lane);
+                nnls_solve_warm<NB, (NB == 2 && VPW == 1)>(S, bd, st[vv], 0.0, false, lane);   // one position slot (k <= nTE); with two voxels per wave the second code path stops the voxel loop from unrolling
                 const double rn = sqrt(sse_of<NB>(S, st[vv], b[vv], lane));
                 if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
                 if (rn < best_r[vv]) {        // np.argmin: first minimum wins
@@ -1585,6 +1594,18 @@ static int fast_kmax(const met2_plan *p, int method)
     while (16 * sizeof(double) * (size_t)col_base(k16 + 1) <= 160 * 1024 - 64) ++k16;
     int k = (3 * p->n_t2 + 4) / 5;
     if (k16 > k) k = k16;
+    if (p->n_t2 > 64) {
+        // two bins per lane: those kernels are compiled for 8 waves per CU (method_max_waves), so the capacity that still lets EIGHT
+        // regions share the LDS -- 71 at nT2 = 120, where 0.6 n = 72 gave 7 (round 3, X2/L2 at 48 x 120 on 32 768 voxels: first pass
+        // 26.1 -> 23.2 ms, clean-up 5.2 -> 6.4 ms; 64 -> 22.4 + 17.7 ms; 80 / 90 / 110 -> 29.0 / 41.4 / 53.3 ms with a clean-up pass
+        // that stays at ~5 ms: a few voxels whose set at the first abscissae is nearly all of the grid.  A middle pass at capacity
+        // 88 or 100 between the two made the clean-up slower, 6.7 -> 10 ms: those voxels outgrow it too and are solved three times) ...
+        int k8 = 8;
+        while (8 * sizeof(double) * (size_t)col_base(k8 + 1) <= 160 * 1024 - 64) ++k8;
+        k = k8;
+        // ... and GCV's region is set by its (m + 1)^2 matrix anyway: the largest factor that fits in it
+        if (method == MET2_GCV) while (col_base(k + 1) <= gcv_lds_doubles(p->n_te, p->n_t2)) ++k;
+    }
     return k < p->n_t2 ? k : 0;
 }
 

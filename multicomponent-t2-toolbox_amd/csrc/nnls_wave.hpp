@@ -182,6 +182,25 @@ __device__ __forceinline__ void clear_bit(u64 (&m)[NB], int idx)
     if (NB == 2 && (idx >> 6)) m[NB - 1] &= ~(1ull << (idx & 63)); else m[0] &= ~(1ull << (idx & 63));
 }
 
+
+// NP = number of register slots that hold POSITION-indexed quantities (y, 1/diag, ord, the rows and columns of the factor): NB in
+// general, 1 while the passive set fits 64 positions.  At two bins per lane every position-indexed vector operation is issued once per
+// slot, and with k <= 64 the second slot is all inactive lanes -- half of the vector instructions of the substitutions, the
+// plane-rotation chains and the row-by-row factorisation did nothing (k ~ 40 at 48 x 120, k <= 48 in the FA walk).  The routines
+// below take NP as a second template argument; bin-indexed quantities (x, h, pos, rows of B and K) keep their NB slots.
+template <int NB, int NP>
+__device__ __forceinline__ double bcastPos(const double (&v)[NB], int idx)
+{
+    if (NP == 1) return bcast(v[0], idx);
+    return bcastN<NB>(v, idx);
+}
+template <int NB, int NP>
+__device__ __forceinline__ int bcastPos_i(const int (&v)[NB], int idx)
+{
+    if (NP == 1) return bcast_i(v[0], idx);
+    return bcastN_i<NB>(v, idx);
+}
+
 __device__ __forceinline__ double band_pick(const double (&b)[5], int d) // d in [-2,2] else 0
 {
     double v = 0.0;
@@ -269,14 +288,14 @@ __device__ __forceinline__ void givens(double a, double b, double &c, double &s,
 // The column loop is unrolled by two with two named prefetch registers: the LDS read issued in one step is
 // consumed a full step later, so the compiler can wait with lgkmcnt(1) instead of draining the read it has
 // just issued (a single rotating register forces lgkmcnt(0) in front of every FMA).
-template <int NB>
+template <int NB, int NP = NB>
 __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<NB> &st, int lane, double (&z)[NB])
 {
     const int k = st.k;
     double y[NB], ra[NB], rb[NB];
     int cb = col_base(k - 1);                                           // column c of the loop below
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NP; ++b) {
         const int pl = lane + 64 * b;
         y[b] = st.y[b];
         ra[b] = (k > 0 && pl < k - 1) ? S.R[cb + pl] : 0.0;             // column k-1
@@ -286,40 +305,40 @@ __device__ __forceinline__ void back_subst(const WaveShared &S, const NnlsState<
     for (; c >= 1; c -= 2) {
         const int cb1 = cb - col_len(c - 1), cb2 = cb1 - col_len(c - 2);   // col_base(c-1), col_base(c-2)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rb[b] = (pl < c - 1) ? S.R[cb1 + pl] : 0.0; }   // column c-1
+        for (int b = 0; b < NP; ++b) { const int pl = lane + 64 * b; rb[b] = (pl < c - 1) ? S.R[cb1 + pl] : 0.0; }   // column c-1
         {
-            double t = (NB == 2 && (c >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
+            double t = (NP == 2 && (c >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
             double s = bcast(t, c & 63);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) y[b] = fma(-ra[b], s, y[b]);        // positions >= c are final
+            for (int b = 0; b < NP; ++b) y[b] = fma(-ra[b], s, y[b]);        // positions >= c are final
         }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; ra[b] = (c >= 2 && pl < c - 2) ? S.R[cb2 + pl] : 0.0; }   // column c-2
+        for (int b = 0; b < NP; ++b) { const int pl = lane + 64 * b; ra[b] = (c >= 2 && pl < c - 2) ? S.R[cb2 + pl] : 0.0; }   // column c-2
         {
             const int c1 = c - 1;
-            double t = (NB == 2 && (c1 >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
+            double t = (NP == 2 && (c1 >> 6)) ? y[NB - 1] * st.rinv[NB - 1] : y[0] * st.rinv[0];
             double s = bcast(t, c1 & 63);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) y[b] = fma(-rb[b], s, y[b]);
+            for (int b = 0; b < NP; ++b) y[b] = fma(-rb[b], s, y[b]);
         }
         cb = cb2;
     }
     // c == 0 needs no update (nothing lies above row 0's diagonal entry); c == -1: done
 #pragma unroll
-    for (int b = 0; b < NB; ++b) z[b] = (lane + 64 * b < k) ? y[b] * st.rinv[b] : 0.0;
+    for (int b = 0; b < NB; ++b) z[b] = (b < NP && lane + 64 * b < k) ? y[b] * st.rinv[b] : 0.0;
 }
 
 // Remove position p from the passive set: delete column p of R and re-triangularise.
-template <int NB>
+template <int NB, int NP = NB>
 __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &st, int p, int lane)
 {
     const int k = st.k;
     MET2_CYC_BEGIN(c_rm);
-    const int tb = bcastN_i<NB>(st.ord, p);
+    const int tb = bcastPos_i<NB, NP>(st.ord, p);
     if (p < k - 1) {
         int cbl[NB];                                                    // col_base of the lane's own (old) column
 #pragma unroll
-        for (int b = 0; b < NB; ++b) cbl[b] = col_base(lane + 64 * b);
+        for (int b = 0; b < NP; ++b) cbl[b] = col_base(lane + 64 * b);
         // rows above p: column c+1 moves into column c.  With the pivot order of reorder_by_x() the variable that leaves sits near the
         // END of the order (k - 1 - p is 1 or 2): then the few columns behind p are moved one by one, lane <-> row; otherwise row by
         // row, lane <-> column (all reads of a row, then its writes).
@@ -328,22 +347,22 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
                 const int src = col_base(c + 1), dst = col_base(c);
                 double v[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; v[b] = (pl < p) ? S.R[src + pl] : 0.0; }
+                for (int b = 0; b < NP; ++b) { const int pl = lane + 64 * b; v[b] = (pl < p) ? S.R[src + pl] : 0.0; }
 #pragma unroll
-                for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; if (pl < p) S.R[dst + pl] = v[b]; }
+                for (int b = 0; b < NP; ++b) { const int pl = lane + 64 * b; if (pl < p) S.R[dst + pl] = v[b]; }
             }
             __builtin_amdgcn_wave_barrier();
         } else
         for (int i = 0; i < p; ++i) {
             double v[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 const int pl = lane + 64 * b;
                 v[b] = (pl >= p && pl <= k - 2) ? S.R[cbl[b] + col_len(pl) + i] : 0.0;   // col_base(pl+1) = col_base(pl) + col_len(pl)
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 const int pl = lane + 64 * b;
                 if (pl >= p && pl <= k - 2) S.R[cbl[b] + i] = v[b];
             }
@@ -351,26 +370,26 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
         // rows p..k-1: chain of plane rotations, owned index = old column index
         double carry[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NP; ++b) {
             const int pl = lane + 64 * b;
             carry[b] = (pl > p && pl < k) ? S.R[cbl[b] + p] : 0.0;
         }
-        double ycar = bcastN<NB>(st.y, p);
+        double ycar = bcastPos<NB, NP>(st.y, p);
         for (int j = p + 1; j < k; ++j) {
             double rowj[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 const int pl = lane + 64 * b;
                 rowj[b] = (pl >= j && pl < k) ? S.R[cbl[b] + j] : 0.0;
             }
-            double a = bcastN<NB>(carry, j), bb = bcastN<NB>(rowj, j);
+            double a = bcastPos<NB, NP>(carry, j), bb = bcastPos<NB, NP>(rowj, j);
             double c, s, sig, sinv;
             givens(a, bb, c, s, sig, sinv);
-            double yj = bcastN<NB>(st.y, j);
+            double yj = bcastPos<NB, NP>(st.y, j);
             double ynew = c * ycar + s * yj;
             ycar = -s * ycar + c * yj;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 const int pl = lane + 64 * b;
                 double nv = c * carry[b] + s * rowj[b];
                 carry[b] = -s * carry[b] + c * rowj[b];
@@ -384,12 +403,12 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
     }
     int ordn[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) ordn[b] = gatherN_i<NB>(st.ord, lane + 64 * b + 1);
+    for (int b = 0; b < NP; ++b) ordn[b] = (NP == 1) ? gather_i(st.ord[0], (lane + 1) & 63) : gatherN_i<NB>(st.ord, lane + 64 * b + 1);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        st.ord[b] = (pl >= p) ? ordn[b] : st.ord[b];
-        st.pos[b] = (st.pos[b] > p) ? st.pos[b] - 1 : st.pos[b];
+        if (b < NP) st.ord[b] = (pl >= p) ? ordn[b] : st.ord[b];                          // by position
+        st.pos[b] = (st.pos[b] > p) ? st.pos[b] - 1 : st.pos[b];                          // by bin
         if (pl == tb) { st.pos[b] = -1; st.x[b] = 0.0; }
     }
     clear_bit<NB>(st.P, tb);
@@ -401,7 +420,7 @@ __device__ __forceinline__ void remove_pos(const WaveShared &S, NnlsState<NB> &s
 // Try to move bin t from Z to P.  Returns false (state untouched) when the column is numerically
 // dependent on the passive columns or -- unless forced -- its trial coefficient is not positive
 // (Lawson-Hanson's two acceptance tests).
-template <int NB>
+template <int NB, int NP = NB>
 __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int t, int lane,
                                            bool forced = false)
 {
@@ -419,7 +438,7 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
     double g[NB], rv[NB];
     int cbl[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NP; ++b) {
         const int pl = lane + 64 * b;
         cbl[b] = col_base(pl);
         double gg = gatherN<NB>(gb, st.ord[b]);                          // position-indexed G[ord_p][t]
@@ -431,32 +450,32 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
     {
         double rw[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) rw[b] = 0.0;
+        for (int b = 0; b < NP; ++b) rw[b] = 0.0;
         int i = 0;
         for (; i + 1 < k; i += 2) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rw[b] = (pl > i + 1 && pl < k) ? S.R[cbl[b] + i + 1] : 0.0; }   // row i+1
+            for (int b = 0; b < NP; ++b) { const int pl = lane + 64 * b; rw[b] = (pl > i + 1 && pl < k) ? S.R[cbl[b] + i + 1] : 0.0; }   // row i+1
             {
-                double tt = (NB == 2 && (i >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
+                double tt = (NP == 2 && (i >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
                 double s = bcast(tt, i & 63);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) g[b] = fma(-rv[b], s, g[b]);      // positions <= i are final
+                for (int b = 0; b < NP; ++b) g[b] = fma(-rv[b], s, g[b]);      // positions <= i are final
             }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; rv[b] = (i + 2 < k && pl > i + 2 && pl < k) ? S.R[cbl[b] + i + 2] : 0.0; }   // row i+2
+            for (int b = 0; b < NP; ++b) { const int pl = lane + 64 * b; rv[b] = (i + 2 < k && pl > i + 2 && pl < k) ? S.R[cbl[b] + i + 2] : 0.0; }   // row i+2
             {
                 const int i1 = i + 1;
-                double tt = (NB == 2 && (i1 >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
+                double tt = (NP == 2 && (i1 >> 6)) ? g[NB - 1] * st.rinv[NB - 1] : g[0] * st.rinv[0];
                 double s = bcast(tt, i1 & 63);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) g[b] = fma(-rw[b], s, g[b]);
+                for (int b = 0; b < NP; ++b) g[b] = fma(-rw[b], s, g[b]);
             }
         }
         // an odd last step i == k-1 updates nobody (no position lies beyond k-1)
     }
     double r[NB], rr = 0.0, ry = 0.0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NP; ++b) {
         r[b] = (lane + 64 * b < k) ? g[b] * st.rinv[b] : 0.0;
         rr = fma(r[b], r[b], rr);
         ry = fma(r[b], st.y[b], ry);
@@ -470,9 +489,11 @@ __device__ __forceinline__ bool try_append(const WaveShared &S, const Band<NB> &
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        if (pl < k) S.R[col_base(k) + pl] = r[b];
-        if (pl == k) { S.R[col_base(k) + k] = rho; st.rinv[b] = rhoinv; st.y[b] = ynew; st.ord[b] = t; }
-        if (pl == t) st.pos[b] = k;
+        if (b < NP) {                                           // by position
+            if (pl < k) S.R[col_base(k) + pl] = r[b];
+            if (pl == k) { S.R[col_base(k) + k] = rho; st.rinv[b] = rhoinv; st.y[b] = ynew; st.ord[b] = t; }
+        }
+        if (pl == t) st.pos[b] = k;                             // by bin
     }
     __builtin_amdgcn_wave_barrier();
     set_bit<NB>(st.P, t);
@@ -536,18 +557,20 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
 // Lawson-Hanson's secondary loop: from a feasible x and a factor consistent with (P, lambda), move to
 // the solution of the passive sub-problem, dropping variables that hit zero on the way.
 // Returns false when the iteration cap is reached.
-template <int NB>
+template <int NB, int NP = NB>
 __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &st, int &iter, int itmax, int lane)
 {
     for (;;) {
         if (++iter > itmax) return false;
         double z[NB], xp[NB], zb[NB], ratio[NB];
         bool neg[NB];
-        if (MET2_DOUBLE == 4) { back_subst<NB>(S, st, lane, z); asm volatile("" :: "v"(z[0])); }
-        back_subst<NB>(S, st, lane, z);                      // position-indexed
+        if (MET2_DOUBLE == 4) { back_subst<NB, NP>(S, st, lane, z); asm volatile("" :: "v"(z[0])); }
+        back_subst<NB, NP>(S, st, lane, z);                  // position-indexed
         bool any = false;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = NP; b < NB; ++b) { neg[b] = false; ratio[b] = 2.0; xp[b] = 0.0; }
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
             const int pl = lane + 64 * b;
             xp[b] = gatherN<NB>(st.x, st.ord[b]);            // x at position
             neg[b] = (pl < st.k) && (z[b] <= 0.0);
@@ -555,7 +578,8 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            double t = gatherN<NB>(z, st.pos[b] < 0 ? 0 : st.pos[b]);   // bin-indexed
+            const int ps = st.pos[b] < 0 ? 0 : st.pos[b];
+            double t = (NP == 1) ? gather(z[0], ps & 63) : gatherN<NB>(z, ps);   // bin-indexed
             zb[b] = (st.pos[b] >= 0) ? t : 0.0;
         }
         if (!any) {
@@ -565,7 +589,7 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
         }
         double rmin = 2.0;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NP; ++b) {
             double r = neg[b] ? xp[b] / (xp[b] - z[b]) : 2.0;
             ratio[b] = (r == r) ? r : 2.0;                   // 0/0: Lawson-Hanson's `alpha > t` is false for NaN
             rmin = fmin(rmin, ratio[b]);
@@ -582,29 +606,29 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
         const int jj = first_bit<NB>(hit);
 #pragma unroll
         for (int b = 0; b < NB; ++b) st.x[b] = (st.pos[b] >= 0) ? fma(alpha, zb[b] - st.x[b], st.x[b]) : 0.0;
-        remove_pos<NB>(S, st, jj, lane);
+        remove_pos<NB, NP>(S, st, jj, lane);
         for (int sweep = 0; sweep < 64 * NB; ++sweep) {   // round-off stragglers (Lawson-Hanson: "any that are nonpositive ...")
             u64 bad[NB];
             bool anyb = false;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = NP; b < NB; ++b) bad[b] = 0ull;
+#pragma unroll
+            for (int b = 0; b < NP; ++b) {
                 double xq = gatherN<NB>(st.x, st.ord[b]);
                 bad[b] = ballot((lane + 64 * b < st.k) && (xq <= 0.0));
                 anyb = anyb || (bad[b] != 0ull);
             }
             if (!anyb) break;
             MET2_STAT(1, sweep + 1);
-            remove_pos<NB>(S, st, first_bit<NB>(bad), lane);
+            remove_pos<NB, NP>(S, st, first_bit<NB>(bad), lane);
         }
     }
 }
 
-// Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
-// warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
-// (P, lam) -- start with the secondary loop instead of from the empty set.
+// The passive-set iteration on NB position slots (the general form).
 template <int NB>
-__device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
-                                             bool warm = false)
+__device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
+                                                   bool warm)
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
@@ -665,6 +689,96 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
     }
 }
 
+// One leg of the passive-set iteration with NP position slots.  NP < NB (one slot: k <= 64) hands over to the general leg when the
+// set is about to outgrow 64 positions: returns false then ("not finished"), with iter / outer / warm carried in the arguments.
+template <int NB, int NP>
+__device__ __forceinline__ bool iterate_leg(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
+                                            bool &warm, int &iter, int &outer)
+{
+    const int n = S.n, itmax = 3 * n;
+    MET2_CYC_BEGIN(c_in0);
+    if (warm && st.k > 0) {
+        warm = false;
+        if (!nnls_inner<NB, NP>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return true; }
+    }
+    warm = false;
+    MET2_CYC_END(2, c_in0);
+    for (; outer <= itmax + 1; ++outer) {                  // every pass runs >= 1 counted inner pass
+        if (st.k >= n || st.k >= mrows) break;
+        if (NP < NB && st.k >= 63) return false;           // the next append would need position 64: the two-slot leg takes over
+        double w[NB];
+        MET2_CYC_BEGIN(c_du);
+        if (MET2_DOUBLE == 2) { dual<NB>(S, bd, st, lam, lane, w); asm volatile("" :: "v"(w[0])); }
+        dual<NB>(S, bd, st, lam, lane, w);
+        MET2_CYC_END(3, c_du);
+        MET2_CYC_ADD(13, 1);
+        if (st.k >= S.kmax) {
+            // capacity of the fast path reached: if a variable still wants to enter, the voxel is redone with kmax = n
+            double vmax = -1.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) vmax = fmax(vmax, ((lane + 64 * b < n) && !((st.P[b] >> lane) & 1ull)) ? w[b] : -1.0);
+            if (wave_max(vmax) > 0.0) st.itmax_hit |= 2;
+            break;
+        }
+        // entering variable: largest positive dual among Z; rejected candidates are skipped
+        u64 rejected[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) rejected[b] = 0ull;
+        bool accepted = false;
+        MET2_CYC_BEGIN(c_ap);
+        for (int tries = 0; tries < 64 * NB; ++tries) {      // each failed try rejects one more bin
+            bool cand[NB];
+            double val[NB], vmax = -1.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                cand[b] = (lane + 64 * b < n) && !((st.P[b] >> lane) & 1ull) && !((rejected[b] >> lane) & 1ull);
+                val[b] = cand[b] ? w[b] : -1.0;
+                vmax = fmax(vmax, val[b]);
+            }
+            const double wmax = wave_max(vmax);
+            if (!(wmax > 0.0)) break;
+            u64 hit[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) hit[b] = ballot(cand[b] && val[b] == wmax);
+            const int t = first_bit<NB>(hit);
+            if (try_append<NB, NP>(S, bd, st, lam, t, lane)) { accepted = true; break; }
+            set_bit<NB>(rejected, t);
+            MET2_STAT(0, tries + 1);
+        }
+        MET2_CYC_END(4, c_ap);
+        MET2_CYC_ADD(14, 1);
+        if (!accepted) break;
+        MET2_CYC_BEGIN(c_in);
+        const bool inner_ok = nnls_inner<NB, NP>(S, st, iter, itmax, lane);
+        MET2_CYC_END(2, c_in);
+        MET2_CYC_ADD(15, 1);
+        if (!inner_ok) { st.itmax_hit |= 1; break; }
+        MET2_STAT(2, outer + 1);
+        MET2_STAT(3, iter);
+    }
+    return true;
+}
+
+#ifndef MET2_ONE_SLOT
+#define MET2_ONE_SLOT 1       // 1: at two bins per lane the position-indexed work runs on one register slot while k <= 64 (0: always two),
+                              //    in the kernels that ask for it (template argument ONE: those with registers to spare -- the GCV kernel at
+                              //    255 VGPRs spilled and lost 31 % with both code paths in it)
+#endif
+// Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
+// warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
+// (P, lam) -- start with the secondary loop instead of from the empty set.
+template <int NB, bool ONE = false>
+__device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
+                                             bool warm = false)
+{
+    if constexpr (NB == 2 && ONE && MET2_ONE_SLOT) {
+        int iter = 0, outer = 0;
+        if (st.k <= 63 && iterate_leg<NB, 1>(S, bd, st, lam, mrows, lane, warm, iter, outer)) return;
+        (void)iterate_leg<NB, NB>(S, bd, st, lam, mrows, lane, warm, iter, outer);
+    } else
+        nnls_iterate_plain<NB>(S, bd, st, lam, mrows, lane, warm);
+}
+
 template <int NB>
 __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 {
@@ -684,7 +798,7 @@ __device__ __forceinline__ void nnls_reset(NnlsState<NB> &st)
 // y comes out of the same sweep (one elimination step per finished row).
 // Returns false -- R is then unusable, ord/pos/P/k/x are untouched -- when a pivot falls under the independence
 // threshold of try_append; the caller re-appends column by column, which drops such columns.
-template <int NB>
+template <int NB, int NP = NB>
 __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
     const int k = st.k, n = S.n;
@@ -694,15 +808,17 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int pl = lane + 64 * b;
-        cbl[b] = col_base(pl);
-        cbc[b] = col_base(min(pl, k - 1));                              // an existing column for the unpredicated reads
-        jc[b] = (unsigned)min(pl, n - 1);
-        const double hh = gatherN<NB>(st.h, st.ord[b]);
-        g[b] = (pl < k) ? hh : 0.0;
+        jc[b] = (unsigned)min(pl, n - 1);                               // by bin: the column a lane loads of every row of B and K
+        if (b < NP) {                                                   // by position
+            cbl[b] = col_base(pl);
+            cbc[b] = col_base(min(pl, k - 1));                          // an existing column for the unpredicated reads
+            const double hh = gatherN<NB>(st.h, st.ord[b]);
+            g[b] = (pl < k) ? hh : 0.0;
+        }
     }
     // rows of B and K for pivots p and p + 1 (clamped to the last pivot)
     auto fetch = [&](int p, double (&vb)[NB], double (&vk)[NB]) {
-        const int t = bcastN_i<NB>(st.ord, min(p, k - 1));
+        const int t = bcastPos_i<NB, NP>(st.ord, min(p, k - 1));
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             vb[b] = ld_row_sel(S.buffer_rows, S.B, t * S.bstride, jc[b]);
@@ -713,11 +829,11 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
     // (the independence test of the pivots is done for all rows at once after the sweep: a non-positive or NaN pivot only
     //  poisons the rows below it, and the whole factor is discarded then)
     auto finish = [&](int i, double (&a)[NB], double (&r)[NB]) {
-        const double d = bcastN<NB>(a, i);
+        const double d = bcastPos<NB, NP>(a, i);
         const double rinv = rsqrt_nr(d);
-        const double yi = bcastN<NB>(g, i) * rinv;
+        const double yi = bcastPos<NB, NP>(g, i) * rinv;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < NP; ++b) {
             const int pl = lane + 64 * b;
             r[b] = a[b] * rinv;                                         // lane i: d * rinv = R[i][i]
             if (pl >= i && pl < k) S.R[cbl[b] + i] = r[b];
@@ -734,7 +850,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
             gdb[b] = (lam != 0.0) ? fma(lam, S.K[jc[b] * n + jc[b]], bd0) : bd0;
         }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) gdp[b] = gatherN<NB>(gdb, st.ord[b]);
+        for (int b = 0; b < NP; ++b) gdp[b] = gatherN<NB>(gdb, st.ord[b]);
     }
     fetch(0, gb0, gk0);
     fetch(1, gb1, gk1);
@@ -752,7 +868,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
             fetch(i + 2, gb0, gk0);
             fetch(i + 3, gb1, gk1);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); }
+            for (int b = 0; b < NP; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); c[b] = gatherN<NB>(t1, st.ord[b]); }
         }
         const double *ci = S.R + cbi, *cj = ci + col_len(i);            // columns i and i + 1
         int j = 0;
@@ -762,7 +878,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
             lds_quad(ci + j, s0, s1, s2, s3);
             lds_quad(cj + j, u0, u1, u2, u3);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 double q0, q1, q2, q3;
                 lds_quad(S.R + cbc[b] + j, q0, q1, q2, q3);
                 a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);      // the two rows are the two independent chains
@@ -776,7 +892,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
             lds_pair(ci + j, s0, s1);
             lds_pair(cj + j, u0, u1);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 double q0, q1;
                 lds_pair(S.R + cbc[b] + j, q0, q1);
                 a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]);
@@ -787,13 +903,13 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
         for (; j < i; ++j) {
             const double s0 = ci[j], u0 = cj[j];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { const double q0 = S.R[cbc[b] + j]; a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]); }
+            for (int b = 0; b < NP; ++b) { const double q0 = S.R[cbc[b] + j]; a[b] = fma(-s0, q0, a[b]); c[b] = fma(-u0, q0, c[b]); }
         }
         double r[NB], r1[NB];
         finish(i, a, r);
-        const double sr = bcastN<NB>(r, i + 1);                         // R[i][i+1]
+        const double sr = bcastPos<NB, NP>(r, i + 1);                         // R[i][i+1]
 #pragma unroll
-        for (int b = 0; b < NB; ++b) c[b] = fma(-sr, r[b], c[b]);
+        for (int b = 0; b < NP; ++b) c[b] = fma(-sr, r[b], c[b]);
         finish(i + 1, c, r1);
         __builtin_amdgcn_wave_barrier();
         cbi += col_len(i) + col_len(i + 1);                             // col_base(i + 2) - col_base(i)
@@ -805,7 +921,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
 #pragma unroll
             for (int b = 0; b < NB; ++b) t0[b] = fma(lam, gk0[b], gb0[b]);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); a2[b] = 0.0; }
+            for (int b = 0; b < NP; ++b) { a[b] = gatherN<NB>(t0, st.ord[b]); a2[b] = 0.0; }
         }
         const double *ci = S.R + cbi;
         int j = 0;
@@ -814,7 +930,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
             double s0, s1, s2, s3;
             lds_quad(ci + j, s0, s1, s2, s3);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NP; ++b) {
                 double q0, q1, q2, q3;
                 lds_quad(S.R + cbc[b] + j, q0, q1, q2, q3);
                 a[b] = fma(-s0, q0, a[b]); a2[b] = fma(-s1, q1, a2[b]);
@@ -824,11 +940,11 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
         for (; j < i; ++j) {
             const double s0 = ci[j];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) a[b] = fma(-s0, S.R[cbc[b] + j], a[b]);
+            for (int b = 0; b < NP; ++b) a[b] = fma(-s0, S.R[cbc[b] + j], a[b]);
         }
         double r[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) a[b] += a2[b];
+        for (int b = 0; b < NP; ++b) a[b] += a2[b];
         finish(i, a, r);
         __builtin_amdgcn_wave_barrier();
     }
@@ -836,7 +952,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
     // try_append at once (NaN from a negative pivot fails the comparison too)
     double dgl[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NP; ++b) {
         const int pl = lane + 64 * b;
         dgl[b] = (pl < k) ? S.R[cbl[b] + pl] : 1.0;
         bad = bad || (ballot((pl < k) && !(dgl[b] * dgl[b] > 1e-14 * gdp[b])) != 0ull);
@@ -844,7 +960,7 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
     if (bad) return false;
     // lane p: 1 / R[p][p] and y_p = g_p / R[p][p] (g_p is final once rows < p are eliminated)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NP; ++b) {
         const int pl = lane + 64 * b;
         const double ri = rcp_nr(dgl[b]);
         st.rinv[b] = (pl < k) ? ri : st.rinv[b];
@@ -1073,23 +1189,27 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
     return true;
 }
 
+#ifndef MET2_ONE_SLOT_REFACTOR
+#define MET2_ONE_SLOT_REFACTOR 1    // 1: with k <= 64 at two bins per lane the warm re-factorisation is the row-by-row form on one slot (0: the blocked MFMA form)
+#endif
 #ifndef MET2_REFACTOR_BLOCKED_FROM
 #define MET2_REFACTOR_BLOCKED_FROM 2        // bins per lane from which the blocked form is used
 #endif
-template <int NB>
+template <int NB, bool ONE = false>
 __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
+    if (NB == 2 && ONE && MET2_ONE_SLOT && MET2_ONE_SLOT_REFACTOR && st.k <= 64) return refactor_rowwise<NB, 1>(S, bd, st, lam, lane);   // k <= 64: one position slot, row by row
     if (NB >= MET2_REFACTOR_BLOCKED_FROM) return refactor_blocked<NB>(S, bd, st, lam, lane);
     if (MET2_DOUBLE == 1) { (void)refactor_rowwise<NB>(S, bd, st, lam, lane); __builtin_amdgcn_wave_barrier(); }
     return refactor_rowwise<NB>(S, bd, st, lam, lane);
 }
 
 // cold-start solve; on return st.x is the solution
-template <int NB>
+template <int NB, bool ONE = false>
 __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
     nnls_reset<NB>(st);
-    nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
+    nnls_iterate<NB, ONE>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
 }
 
 // Pivot order for a warm start: the passive bins by DESCENDING x.  The re-factorisation builds the factor in whatever order it is
@@ -1153,14 +1273,14 @@ __device__ __forceinline__ void reorder_by_x(const WaveShared &S, NnlsState<NB> 
 // rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
 // strictly convex problem does not depend on the starting point, so this returns the same x as the
 // cold start up to rounding; it only skips the passes that would rebuild the same passive set.
-template <int NB>
+template <int NB, bool ONE = false>
 __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
     const int kold = st.k;
-    if (kold == 0) { nnls_solve<NB>(S, bd, st, lam, aug, lane); return; }
+    if (kold == 0) { nnls_solve<NB, ONE>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
     if (NB >= MET2_REORDER && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
-    if (!refactor<NB>(S, bd, st, lam, lane)) {
+    if (!refactor<NB, ONE>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
         int ordold[NB];
 #pragma unroll
@@ -1176,7 +1296,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     }
     MET2_CYC_END(1, c_ref);
     MET2_CYC_ADD(12, 1);
-    nnls_iterate<NB>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
+    nnls_iterate<NB, ONE>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
 }
 
 // D x  (lane e < m holds (D x)_e), using the passive set of st
