@@ -681,8 +681,10 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                     canon = (evi == 0) ? gm_ * 10.0 : (evi == 1 ? canon + gm_ * (10.0 - canon) : (evi == 2 ? gm_ * 10.0 * (1.0 - gm_) : canon * (1.0 - gm_)));
                     const bool is_canon = fabs(x - canon) <= 1e-12 * canon;
 #endif
-                    if (st.itmax_hit & 2) return 0.0;               // the passive set hit the pass's capacity: the voxel is solved again in the
-                                                                    // next pass, the rest of its Brent path here costs nothing
+                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // the passive set hit the pass's capacity: the voxel is solved again in the
+                                                                    // next pass, the rest of its Brent path here costs nothing (two bins per lane,
+                                                                    // where 5-10 % of the voxels do; at one bin per lane ~1 % do and the test cost
+                                                                    // the X2 kernel two more spilled registers)
                     nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
                     double SSEr = sse_of<NB>(S, st, b, lane);
 #ifdef MET2_CYCSTATS
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                     for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
                 }, 0.0, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                if (lam != last_x && !(st.itmax_hit & 2)) {
+                if (lam != last_x && !(NB == 2 && (st.itmax_hit & 2))) {
                     int kk = 0;
 #pragma unroll
                     for (int bb = 0; bb < NB; ++bb) {
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 int keep_p[NS][NB];
                 for (int i = 0; i < A.nlam; ++i) {
                     double lam = A.lam_grid[i];
-                    if (st.itmax_hit & 2) break;                    // capacity hit: solved again in the next pass
+                    if (NB == 2 && (st.itmax_hit & 2)) break;       // capacity hit: solved again in the next pass
                     nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
                     double sse = sse_of<NB>(S, st, b, lane);
                     double sn = seminorm2<NB>(bd, st.x, n, lane);
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                             for (int bb = 0; bb < NB; ++bb) { keep_x[q][bb] = st.x[bb]; keep_p[q][bb] = (st.pos[bb] + 1) | (st.ord[bb] << 9); }
                         }
                 }
-                if (!(st.itmax_hit & 2)) {
+                if (!(NB == 2 && (st.itmax_hit & 2))) {
                 int corner = select_corner_dev(le, ln, A.nlam, lane);
                 regv = lamv = A.lam_grid[corner];
                 {
@@ -795,13 +797,13 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
-                    if (st.itmax_hit & 2) return 0.0;               // capacity hit: solved again in the next pass
+                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     return gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
                 }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
-                if (!(st.itmax_hit & 2)) nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             }
             if (METHOD >= 10) {
