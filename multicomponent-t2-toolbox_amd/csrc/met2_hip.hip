@@ -266,6 +266,8 @@ struct FitArgs {
     const char *seed;                     // [nfa] SeedRec: first-Brent-point seeds of the method (seed_kernel), or NULL
     const double *btab;                   // BayesReg: [nfa][nbtab][btab_stride] factors of B + lambda_j K and, behind each, log det (bayes_table_kernel), or NULL
     int nbtab, btab_stride;
+    double *chol;                         // BayesReg at two bins per lane: [grid * waves][chol_stride] scratch for the factor (chol_lean), or NULL
+    int chol_stride;
     double blam[MET2_BAYES_TABLE];        // the shared Brent abscissae lambda_j
 };
 
@@ -463,7 +465,7 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
     const int base = method >= 10 ? method - 10 : method;
     if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
                                                                       // one bin per lane: the latency-bound recurrences want waves, the spills of a 128-VGPR build go to HBM
-    if (base == MET2_BAYESREG) return (nb == 2) ? 4 : MET2_BAYES_WAVES;  // two bins per lane: the full 120 x 120 factor leaves room for 2 waves per CU
+    if (base == MET2_BAYESREG) return (nb == 2) ? 8 : MET2_BAYES_WAVES;  // two bins per lane: 241 VGPRs; the factor is built a block row at a time (chol_lean)
     // two bins per lane: the factor's LDS footprint (kmax = 72 at nT2 = 120) holds 7 waves per CU anyway, so those kernels are
     // compiled for 8 (256 VGPRs) instead of spilling at 128 (X2 at 48 x 120: 103 spilled VGPRs)
     if (base <= MET2_LCURVE) return (nb == 2) ? 8 : 16;
@@ -774,7 +776,9 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
                 int flag, ev = 0;
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
+                double *cholG = (NB == 2 && A.chol) ? A.chol + (size_t)(blockIdx.x * (unsigned)A.waves + (unsigned)wave) * (size_t)A.chol_stride : nullptr;
                 double lam = fminbound_dev([&](double x) {
+                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
                     nnls_solve_warm<NB>(S, bd, st, x, true, lane);
                     BayesTable tab{nullptr, 0.0};
                     if (A.btab && ev < A.nbtab) {                  // still on the abscissae every voxel shares?  (a rounding-level match: the table's
@@ -785,11 +789,11 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                         }
                     }
                     ++ev;
-                    return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab);
+                    return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab, cholG);
                 }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
-                nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
@@ -1473,6 +1477,7 @@ struct met2_plan {
                                                           // flip angle 0): only then is the seeded start the cold start's solution
     double *dH = nullptr; int64_t cap_h = 0;              // FA walk: h of every flip angle for one pass of voxels (fa_project_kernel), grown on demand
     double *dBtab = nullptr; int btab_stride = 0;         // BayesReg factor tables [nfa][MET2_BAYES_TABLE][btab_stride] (built with the seeds)
+    double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
     int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
     bool err_pending = false;
@@ -1555,6 +1560,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, int kmax_
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
     g.wave_doubles = col_base(g.kmax);                                 // the factor, packed by columns without padding (nnls_wave.hpp)
     if (base == MET2_GCV && gcv_lds_doubles(m, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(m, n);      // M ((m+1)^2) + vectors + support list
+    if (method == MET2_BAYESREG && g.nb == 2 && chol_panel_doubles(n) > g.wave_doubles) g.wave_doubles = chol_panel_doubles(n);   // chol_lean's 16-row panel
     g.wave_doubles = (g.wave_doubles + 1) & ~1;                        // every wave's region starts 16-byte aligned
     // D, D^T, B and K are read through L1/L2: with warm starts a lambda evaluation reads only ~k rows of B, and the LDS is worth
     // more as room for resident waves (measured on X2/L2 in round 1: staged 8 waves 1.555 M voxels/s, unstaged 11 waves 1.821 M)
@@ -1586,7 +1592,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, int kmax_
 // full n x n region (BayesReg) or their own matrix (GCV) do not use it.
 static int fast_kmax(const met2_plan *p, int method)
 {
-    if (method == MET2_BAYESREG || method >= 10) return 0;
+    if (method >= 10 || (method == MET2_BAYESREG && p->n_t2 <= 64)) return 0;     // (BayesReg at one bin per lane factorises n x n in the wave's region)
     { const int kk = tuning_env("MET2_KMAX", 8, p->n_t2 - 1, -1); if (kk > 0) return kk; }
     // the largest capacity that still lets 16 waves share the LDS, but not below 0.6 n
     // (measured on X2/L2, nT2 = 60: kmax 48 -> 1.95 M voxels/s, 50 -> 2.10 M, 52 (14 waves) -> 2.03 M, 60 (11 waves) -> 1.84 M;
@@ -1985,7 +1991,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH};
+    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -2281,6 +2287,18 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
         A.seed = p->dSeed + sizeof(SeedRec) * (size_t)slot * p->n_fa;
     }
     A.btab = nullptr; A.nbtab = 0; A.btab_stride = p->btab_stride;
+    A.chol = nullptr; A.chol_stride = 0;
+    if (method == MET2_BAYESREG && !objgrid && g.nb == 2) {
+        // chol_lean's scratch: one packed factor per wave of the widest launch (first pass; the clean-up pass has fewer waves)
+        const int stride = (col_base(p->n_t2) + 15) & ~15;
+        const int64_t need = (int64_t)g.grid * (kfast ? std::max(g.waves, g2.waves) : g.waves) * stride;
+        if (p->cap_chol < need) {
+            if (p->dChol) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(p->dChol)); p->dChol = nullptr; p->cap_chol = 0; }
+            HIPCHK(hipMalloc(&p->dChol, sizeof(double) * (size_t)need));
+            p->cap_chol = need;
+        }
+        A.chol = p->dChol; A.chol_stride = stride;
+    }
     for (int j = 0; j < (MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1); ++j) A.blam[j] = p->blam[j];
     if (MET2_BAYES_TABLE > 0 && method == MET2_BAYESREG && !objgrid && p->dBtab && p->seeds_valid && p->seeds_ok && !tuning_env("MET2_NO_BAYES_TABLE", 0, 1, 0)) {
         A.btab = p->dBtab; A.nbtab = MET2_BAYES_TABLE;

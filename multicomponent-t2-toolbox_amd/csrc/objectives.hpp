@@ -196,6 +196,196 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
     return true;
 }
 
+// The same factor with the LDS holding ONE block row at a time (two bins per lane: the full 120 x 120 triangle is 58 KB, two waves per
+// CU; the 16-row panel is 16 KB and shares the region of the solver's factor, eight waves per CU).  Left-looking by block rows of 16:
+//   1. the panel P (rows r0 .. r0 + 15 of A = beta B + beta lam K, columns >= r0; column c at P + 17 c: the odd stride keeps a
+//      wave-wide read of one row of all columns off the same banks) is filled from the L2-resident rows of B and K;
+//   2. every 16 x 16 tile of the panel takes  C -= U(j, block)^T U(j, tile)  from every FINISHED block row j -- four
+//      v_mfma_f64_16x16x4 per (tile, j), operands straight from the wave's scratch in global memory G (packed by columns like the
+//      plan-level tables: entry (r, c) at col_base(c) + r), the same 336 MFMAs at n = 120 as the right-looking form;
+//   3. the block's rows are finished in the panel exactly as in chol_full (a);
+//   4. the finished rows go to G, 16 lanes per column (128 contiguous bytes each).
+// G is written and read by this wave only; the workgroup-scope fences order its stores before the loads of the next block row and
+// of upper_times (one CU, one vector L1).  bayes_objective reads (U f) from G as it does from a table.
+constexpr int MET2_PANEL_STRIDE = 17;
+__host__ __device__ inline int chol_panel_doubles(int n) { return n * MET2_PANEL_STRIDE; }
+template <int NB>
+__device__ __forceinline__ bool chol_lean(const WaveShared &S, double beta, double lam, int lane, double &det_u, double *__restrict__ G)
+{
+    lane = lane_opaque(lane);
+    constexpr int PS = MET2_PANEL_STRIDE;
+    const int n = S.n;
+    const double bl = beta * lam;
+    double *P = S.R;
+    int pc[NB];
+    unsigned jc[NB];
+    double diag[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int pl = lane + 64 * b;
+        jc[b] = (unsigned)min(pl, n - 1);
+        pc[b] = (int)jc[b] * PS;                                      // an existing column for the unpredicated reads
+        diag[b] = 1.0;
+    }
+    const int li = lane & 15, lk = lane >> 4;
+    const int nt = (n + 15) >> 4;
+    for (int kb = 0; kb < nt; ++kb) {
+        const int r0 = 16 * kb, r1 = min(n, r0 + 16);
+        // ---- 1. rows r0 .. r1 - 1 of A into the panel, four rows of B and K in flight
+        for (int j = r0; j < r1; j += 4) {
+            double vb[4][NB], vk[4][NB];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = min(j + q, n - 1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    vb[q][b] = ld_row_sel(S.buffer_rows, S.B, jj * S.bstride, jc[b]);
+                    vk[q][b] = ld_row_sel(S.buffer_rows, S.K, jj * n, jc[b]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int c = lane + 64 * b;
+                    if (j + q < r1 && c >= r0 && c < n) P[pc[b] + (j + q - r0)] = fma(bl, vk[q][b], beta * vb[q][b]);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 2. the finished block rows' contribution, on the matrix cores
+        if (kb > 0) {
+            const int ca = min(r0 + li, n - 1);                       // this lane's column inside the block's own tile column
+            const double *ga = G + col_base(ca) + lk;
+            const bool va = r0 + li < n;
+            for (int tj = kb; tj < nt; ++tj) {
+                const int cc = 16 * tj + li;
+                const int ccl = min(cc, n - 1);
+                const double *gb = G + col_base(ccl) + lk;
+                const bool vbn = cc < n;
+                met2_d4 acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int rl = lk + 4 * v;                        // row r0 + rl of the panel
+                    const double t = P[ccl * PS + rl];
+                    acc[v] = (vbn && r0 + rl < r1) ? t : 0.0;
+                }
+#pragma clang loop unroll_count(2)
+                for (int j = 0; j < kb; ++j) {
+                    double aop[4], bop[4];
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {            // rows 16 j + 4 sidx + lk of the finished factor: always above the columns read
+                        const double a = ga[16 * j + 4 * sidx], bq = gb[16 * j + 4 * sidx];
+                        aop[sidx] = va ? -a : 0.0;
+                        bop[sidx] = vbn ? bq : 0.0;
+                    }
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sidx], bop[sidx], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int rl = lk + 4 * v;
+                    if (vbn && r0 + rl < r1) P[ccl * PS + rl] = acc[v];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- 3. the block's rows, two at a time (chol_full (a), on the panel)
+        auto finish = [&](int r, double (&a)[NB], double (&u)[NB]) -> bool {
+            const double d = bcastN<NB>(a, r);
+            const double rinv = rsqrt_nr(d);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int c = lane + 64 * b;
+                u[b] = a[b] * rinv;                                   // lane r: d * rinv = U[r][r]
+                if (c >= r && c < n) P[pc[b] + (r - r0)] = u[b];
+                if (c == r) diag[b] = u[b];
+            }
+            return d > 0.0;                                           // scipy raises LinAlgError otherwise
+        };
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {                                  // r is even (r0 is a multiple of 16)
+            double a[NB], c2[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int c = lane + 64 * b;
+                double a0, c0;
+                lds_pair(P + pc[b] + (r - r0), a0, c0);               // rows r, r + 1 of the lane's column
+                a[b] = (c >= r && c < n) ? a0 : 0.0;
+                c2[b] = (c > r && c < n) ? c0 : 0.0;
+            }
+            const double *cr = P + r * PS, *cr1 = cr + PS;            // columns r and r + 1 (panel rows 0 .. r - r0 - 1 = rows above in the block)
+            int j = 0;
+            const int ja = r - r0;
+#pragma clang loop unroll(disable)
+            for (; j + 4 <= ja; j += 4) {
+                double s0, s1, s2, s3, t0, t1, t2, t3;
+                lds_quad(cr + j, s0, s1, s2, s3);
+                lds_quad(cr1 + j, t0, t1, t2, t3);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1, q2, q3;
+                    lds_quad(P + pc[b] + j, q0, q1, q2, q3);
+                    a[b] = fma(-s0, q0, a[b]); c2[b] = fma(-t0, q0, c2[b]);
+                    a[b] = fma(-s1, q1, a[b]); c2[b] = fma(-t1, q1, c2[b]);
+                    a[b] = fma(-s2, q2, a[b]); c2[b] = fma(-t2, q2, c2[b]);
+                    a[b] = fma(-s3, q3, a[b]); c2[b] = fma(-t3, q3, c2[b]);
+                }
+            }
+            if (j < ja) {                                             // r - r0 is even: two rows left
+                double s0, s1, t0, t1;
+                lds_pair(cr + j, s0, s1);
+                lds_pair(cr1 + j, t0, t1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1;
+                    lds_pair(P + pc[b] + j, q0, q1);
+                    a[b] = fma(-s0, q0, a[b]); c2[b] = fma(-t0, q0, c2[b]);
+                    a[b] = fma(-s1, q1, a[b]); c2[b] = fma(-t1, q1, c2[b]);
+                }
+            }
+            double u[NB], w[NB];
+            if (!finish(r, a, u)) return false;
+            const double su = bcastN<NB>(u, r + 1);                   // U[r][r+1]
+#pragma unroll
+            for (int b = 0; b < NB; ++b) c2[b] = fma(-su, u[b], c2[b]);
+            if (!finish(r + 1, c2, w)) return false;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (r < r1) {                                                 // odd n: the last row on its own
+            double a[NB], u[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int c = lane + 64 * b; const double a0 = P[pc[b] + (r - r0)]; a[b] = (c >= r && c < n) ? a0 : 0.0; }
+            const double *cr = P + r * PS;
+            for (int j = 0; j + 2 <= r - r0; j += 2) {
+                double s0, s1;
+                lds_pair(cr + j, s0, s1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    double q0, q1;
+                    lds_pair(P + pc[b] + j, q0, q1);
+                    a[b] = fma(-s0, q0, a[b]);
+                    a[b] = fma(-s1, q1, a[b]);
+                }
+            }
+            if (!finish(r, a, u)) return false;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- 4. the finished rows to G: lane -> (column c0 + (lane >> 4), row r0 + (lane & 15))
+        for (int c0 = r0; c0 < n; c0 += 4) {
+            const int c = c0 + lk, row = r0 + li;
+            if (c < n && row < r1 && row <= c) G[col_base(c) + row] = P[c * PS + li];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    double dp = 1.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) dp *= (lane + 64 * b < n) ? diag[b] : 1.0;
+    det_u = wave_prod(dp);
+    return true;
+}
+
 // (U f)_i for a factor packed by columns at `U` (the wave's LDS region, or a plan-level table in global memory); the owner of row i
 // gets row i . f.  Only the columns of the passive bins are visited -- f is zero elsewhere (k ~ 20 of n = 60 columns).
 template <int NB>
@@ -247,7 +437,7 @@ struct BayesTable {
 // bayesian_interpolation.py:107-126, given the NNLS solution st.x at lambda = x
 template <int NB>
 __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, BayesCtx &bc,
-                                                  double x, double b, int lane, BayesTable tab = BayesTable{nullptr, 0.0})
+                                                  double x, double b, int lane, BayesTable tab = BayesTable{nullptr, 0.0}, double *G = nullptr)
 {
     const int n = S.n, m = S.m;
     const double beta = bc.beta;
@@ -270,12 +460,13 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 #endif
     } else {
         double det_u;
-        if (!chol_full<NB>(S, bd, beta, x, lane, det_u)) { bc.failed = 1; return NAN; }
+        // G: the wave's scratch in global memory -- the factor is built one block row at a time (two bins per lane)
+        if (!(G ? chol_lean<NB>(S, beta, x, lane, det_u, G) : chol_full<NB>(S, bd, beta, x, lane, det_u))) { bc.failed = 1; return NAN; }
 #ifdef MET2_CYCSTATS
         const unsigned long long c1 = __builtin_readcyclecounter();
         stw.cyc[5] += c1 - c0;
 #endif
-        upper_times<NB>(S.R, st, lane, uf);
+        upper_times<NB>(G ? G : S.R, st, lane, uf);
         log_det_u = log(det_u);
 #ifdef MET2_CYCSTATS
         stw.cyc[6] += __builtin_readcyclecounter() - c1;
