@@ -207,6 +207,8 @@ __device__ __forceinline__ bool chol_full(const WaveShared &S, const Band<NB> &b
 //   4. the finished rows go to G, 16 lanes per column (128 contiguous bytes each).
 // G is written and read by this wave only; the workgroup-scope fences order its stores before the loads of the next block row and
 // of upper_times (one CU, one vector L1).  bayes_objective reads (U f) from G as it does from a table.
+// BayesReg/InvT2 at 48 x 120: 260 k -> 742 k voxels/s (profiles/r03_other_ab.txt).  At one bin per lane the 14.6 KB factor already lets 11
+// waves share the LDS and 168 VGPRs allow 12: measured the same with and without (223.9 ms per Mi voxels), so chol_full stays there.
 constexpr int MET2_PANEL_STRIDE = 17;
 __host__ __device__ inline int chol_panel_doubles(int n) { return n * MET2_PANEL_STRIDE; }
 template <int NB>
@@ -495,9 +497,10 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // gives   trace(Dr G^+ Dr^T) = sum_{kept i} (1 - U[m][i]^2),   kept: sigma_i^2 > eps k sigma_max^2.
 // sigma_i^2 and U[m][i] are the eigenvalues of M = E E^T ((m+1) x (m+1), 33 x 33 or 49 x 49 whatever the support size) and the
 // m-th components of its eigenvectors.  Direct method, no sweeps:
-//   1. M = A A^T with A = E, its sqrt(c) row moved to the front -- the batched Gram contraction of the path, on the matrix
-//      cores: v_mfma_f64_16x16x4 tiles whose operands are gathered straight from the L2-resident D^T rows of the support
-//      (nothing of E is staged); the symmetric result lands in the wave's LDS region;
+//   1. M = A A^T with A = E, its sqrt(c) row moved to the front: M = [[c k, sqrt(c) b^T], [sqrt(c) b, C]], b = Dr 1, C = Dr Dr^T.
+//      C is the batched Gram contraction of the path, on the matrix cores: v_mfma_f64_16x16x4 tiles whose operands are gathered
+//      straight from the L2-resident D^T rows of the support (nothing of E is staged); the symmetric result lands in the wave's LDS
+//      region.  b stays in a register per lane: it feeds the first reflector only;
 //   2. Householder tridiagonalisation T = Q^T M Q, lane <-> row.  The reflectors never touch index 0, so e_0^T Q = e_0^T and
 //      U[m][i] is the FIRST component of the i-th eigenvector of T;
 //   3. every lane isolates one eigenvalue of T by bisection on Sturm counts (LAPACK dstebz's recurrence; the midpoints are
@@ -511,14 +514,21 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // ------------------------------------------------------------------------------------------
 
 
-// LDS doubles a wave needs for it: M (n rows of stride np, three zero padding columns for the 4-wide loops), two padded
-// Householder vectors and the support list
-// Row stride of M: >= n + 3 (the four-wide sweeps run into zero padding), even (every row 16-byte aligned: the sweeps read and
-// write with ds_read/write_b128) and = 2 mod 4: then the 16 lanes of a b128 lane group, each on its own row, fall on 16
-// different four-dword bank groups (2 np mod 64 is an odd multiple of 4) -- conflict-free.
-__host__ __device__ inline int gcv_row_stride(int m) { int np = m + 4; while ((np & 3) != 2) ++np; return np; }
-__host__ __device__ inline int gcv_vec_len(int m) { return (m + 4 + 1) & ~1; }          // n + 3 entries, padded to even
-__host__ __device__ inline int gcv_lds_doubles(int m, int kcap) { const int n = m + 1; return n * gcv_row_stride(m) + 3 * gcv_vec_len(m) + (kcap + 1) / 2 + 2; }
+// LDS doubles a wave needs for it.  Only C = Dr Dr^T (m x m) is kept in LDS: row and column 0 of M -- sqrt(c) (Dr 1) -- feed the FIRST
+// reflector alone and live in a register per lane (round 3; with the 49 x 54 block of M a wave's region was 22.9 KB and a CU held seven;
+// 48 x 50 + vectors = 20.4 KB lets it hold the eight waves the kernel is compiled for: DESIGN 6.3).
+// Columns: m rounded up to the four-wide sweeps (zero padding, as for the three Householder vectors).  Row stride: >= that, even (every
+// row 16-byte aligned: the sweeps read and write with ds_read/write_b128) and = 2 mod 4: then the 16 lanes of a b128 lane group, each
+// on its own row, fall on 16 different four-dword bank groups (2 np mod 64 is an odd multiple of 4) -- conflict-free.
+// The support list (read by the Gram contraction only) shares the room of the vectors (written after it).
+__host__ __device__ inline int gcv_cols(int m) { return (m + 3) & ~3; }
+__host__ __device__ inline int gcv_row_stride(int m) { int np = gcv_cols(m); while ((np & 3) != 2) ++np; return np; }
+__host__ __device__ inline int gcv_vec_len(int m) { return gcv_cols(m); }
+__host__ __device__ inline int gcv_lds_doubles(int m, int kcap)
+{
+    const int vec = 3 * gcv_vec_len(m), lst = (kcap + 1) / 2 + 2;
+    return m * gcv_row_stride(m) + (vec > lst ? vec : lst);
+}
 
 // Sturm count: number of eigenvalues < x (<= x up to the measure-zero case of an exactly vanishing minor) of the symmetric
 // tridiagonal matrix given as (d_j, e_{j-1}^2) pairs, by the sign changes of the leading principal minors
@@ -594,13 +604,14 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 #else
 #define MET2_GCV_LAP(slot)
 #endif
-    const int m = S.m, n = m + 1, np = gcv_row_stride(m);
-    double *M = S.R;                         // [n][np], row a of lane a; row/column 0 = the sqrt(c) row of E
-    double *vb = M + n * np;                 // [n + 3] Householder vector, zero padded
-    double *wb = vb + gcv_vec_len(m);        // [n + 3]
-    double *vb2 = wb + gcv_vec_len(m);       // [n + 3] the Householder vectors alternate between vb and vb2
-    double dj = 0.0, ej = 0.0;               // lane j: T[j][j], T[j+1][j]
+    const int m = S.m, n = m + 1, np = gcv_row_stride(m);      // n: order of T
+    double *M = S.R;                         // C = M[1.., 1..]: [m][np], lane a <-> row a of C = row a + 1 of M
+    double *vb = M + m * np;                 // [gcv_cols] Householder vector, zero padded (the support list sits here during step 1)
+    double *wb = vb + gcv_vec_len(m);
+    double *vb2 = wb + gcv_vec_len(m);       // the Householder vectors alternate between vb and vb2
+    double dj = 0.0, ej = 0.0;               // lane j: T[j][j], T[j+1][j] of the (m + 1) x (m + 1) tridiagonal form
     if (!reuse) {
+    const int n = m;                         // (inside this block: the order of C)
     // ---- 1. M = A A^T on the matrix cores
     {
         const int li = lane & 15, lk = lane >> 4;
@@ -609,15 +620,15 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
             for (int tj = ti; tj < nt; ++tj) {
                 met2_d4 acc = {0.0, 0.0, 0.0, 0.0};
                 const int ra = 16 * ti + li, rb = 16 * tj + li;
-                const int ea = min(max(ra - 1, 0), m - 1), eb = min(max(rb - 1, 0), m - 1);
+                const int ea = min(ra, m - 1), eb = min(rb, m - 1);
                 for (int r0 = 0; r0 < k; r0 += 16) {            // four k-steps per batch: eight operand loads in flight
                     double a[4], b[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rr = r0 + 4 * q + lk;
                         const double *col = S.DtG + (size_t)list[min(rr, k - 1)] * S.dtstride;    // column s_rr of D, contiguous in D^T
-                        const double va = (ra == 0) ? sc : col[ea];
-                        const double vbb = (rb == 0) ? sc : col[eb];
+                        const double va = col[ea];
+                        const double vbb = col[eb];
                         a[q] = (rr < k && ra < n) ? va : 0.0;
                         b[q] = (rr < k && rb < n) ? vbb : 0.0;
                     }
@@ -631,8 +642,26 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
                     if (row < n && c < n) { M[row * np + c] = acc[v]; M[c * np + row] = acc[v]; }
                 }
             }
-        if (lane < n) { M[lane * np + n] = 0.0; M[lane * np + n + 1] = 0.0; M[lane * np + n + 2] = 0.0; }
-        if (lane < 3) { vb[n + lane] = 0.0; wb[n + lane] = 0.0; vb2[n + lane] = 0.0; }
+        // column 0 of M below its diagonal: b = Dr 1 (row sums of D over the support), lane e <-> echo e; parked in wb until the
+        // first reflector has been built from it (wb takes that step's w afterwards)
+        double bvec = 0.0;
+        {
+            const int le = min(lane, m - 1);
+            for (int r0 = 0; r0 < k; r0 += 4) {
+                double t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = S.DtG[(size_t)list[min(r0 + q, k - 1)] * S.dtstride + le];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bvec += (r0 + q < k) ? t[q] : 0.0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                 // (the list is dead from here: the vectors' room takes b and the padding)
+        if (lane < m) wb[lane] = sc * bvec;
+        const int pad = gcv_cols(m) - m;                                 // 0 .. 3 zero columns / entries
+        for (int q = 0; q < pad; ++q) {
+            if (lane < n) M[lane * np + n + q] = 0.0;
+            if (lane == 0) { vb[n + q] = 0.0; wb[n + q] = 0.0; vb2[n + q] = 0.0; }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     MET2_GCV_LAP(8);
@@ -663,9 +692,10 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
         }
         __builtin_amdgcn_wave_barrier();
     };
-    for (int j = 0; j + 2 < n; ++j) {
+    double e_pre = 0.0;                                               // T[1][0] (at c = 1): comes out of the reflector built from b
+    for (int j = -1; j + 2 < n; ++j) {                                // j = -1: column 0 of M, i.e. b; then the columns of C
         const bool below = lane > j && lane < n;
-        double mj = Mrow[j];
+        double mj = (j < 0) ? wb[min(lane, n - 1)] : Mrow[max(j, 0)];
         if (pend) {                                                   // column j of the matrix the pending update produces
             const double vj = bcast(vp, j), wj = bcast(wp, j);
             mj = fma(-wp, vj, fma(-vp, wj, mj));
@@ -676,6 +706,7 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
         const double xn2 = wave_sum((lane > j + 1) ? x * x : 0.0);
         if (xn2 == 0.0) {                                             // column already in tridiagonal form
             if (lane == j) ej = x0;
+            if (j < 0) e_pre = x0;
             if (pend) { flush(j + 1); pend = false; }
             continue;
         }
@@ -722,12 +753,18 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
         if (lane < n) wb[lane] = w;                                   // (the pass above was the last reader of the old w)
         __builtin_amdgcn_wave_barrier();
         if (lane == j) ej = alpha;
+        if (j < 0) e_pre = alpha;
         vp = v; wp = w; pend = true;
         double *tswap = vprev; vprev = vnext; vnext = tswap;
     }
     if (pend) flush(n - 2);                                            // the trailing 2 x 2 block still waits for the last update
     if (lane == n - 2) { dj = Mrow[n - 2]; ej = M[(n - 1) * np + n - 2]; }
     if (lane == n - 1) { dj = Mrow[n - 1]; ej = 0.0; }
+    {   // lane a holds the entries of C's row a = row a + 1 of T: one lane up; lane 0 takes (d_0 set below, e_pre)
+        const double dsh = gather(dj, (lane + 63) & 63), esh = gather(ej, (lane + 63) & 63);
+        dj = (lane >= 1 && lane <= m) ? dsh : 0.0;
+        ej = (lane == 0) ? e_pre : ((lane >= 1 && lane <= m) ? esh : 0.0);
+    }
 #pragma unroll
     for (int q = 0; q < MET2_GCV_CACHE; ++q) if (slot == q) { tc.d[q] = dj; tc.e[q] = ej; }
     } else {
@@ -881,8 +918,8 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     const bool reuse = slot >= 0;
     if (!reuse) slot = tc.next;
     tc.next = (slot + 1 == MET2_GCV_CACHE) ? 0 : slot + 1;             // two entries: a miss overwrites the one not used last
-    // support list (ascending bins) behind the matrices in the wave's LDS region
-    int *list = (int *)(S.R + (m + 1) * gcv_row_stride(m) + 3 * gcv_vec_len(m));
+    // support list (ascending bins) behind C in the wave's LDS region (where the Householder vectors go once the Gram contraction has read it)
+    int *list = (int *)(S.R + m * gcv_row_stride(m));
     if (!reuse) {
         int base = 0;
 #pragma unroll
