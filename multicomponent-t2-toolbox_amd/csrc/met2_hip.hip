@@ -1617,6 +1617,20 @@ static int fast_kmax(const met2_plan *p, int method)
     return k < p->n_t2 ? k : 0;
 }
 
+// Middle rung of the capacity ladder, GCV at two bins per lane only (BayesReg's few clean-up voxels measure the same with and without): the full n x n factor of the clean-up pass (58 KB at nT2 = 120)
+// leaves a CU two waves; the largest capacity that gives it three is 116, and on the [1e-8, 10] interval of algorithms.py:279 the
+// sets that outgrow the first pass stay under it (131 072 voxels of configs[4] with a FIRST pass at capacity 116: 0.07 ms of clean-up
+// left).  X2's interval visits 6.18 for every voxel, where those sets are the whole grid (clean-up 4.96 ms after a first pass at
+// 118): for it a middle pass means solving them three times (measured: 6.7 -> 10 ms), so it gets none.  0: no middle pass.
+static int mid_kmax(const met2_plan *p, int method, int kfast)
+{
+    if (!kfast || p->n_t2 <= 64 || method != MET2_GCV) return 0;
+    { const int kk = tuning_env("MET2_KMID", 0, p->n_t2 - 1, -1); if (kk >= 0) return kk > kfast ? kk : 0; }
+    int k3 = kfast;
+    while (k3 + 1 < p->n_t2 && 3 * sizeof(double) * (size_t)col_base(k3 + 1) <= 160 * 1024 - 64) ++k3;
+    return (k3 >= kfast + 8 && k3 < p->n_t2) ? k3 : 0;
+}
+
 template <int METHOD, int NB, bool SECOND>
 static int launch_fit_nb(const FitArgs &A, const LaunchGeom &g, hipStream_t s)
 {
@@ -2319,6 +2333,21 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
         HIPCHK(hipGetLastError());
         FitArgs A2 = A;
+        const int kmid = mid_kmax(p, method, kfast);
+        if (kmid) {                                         // middle rung: same kernel at capacity kmid; what still overflows is queued once more
+            LaunchGeom gm;
+            rc = fit_geometry(p, method, gm, kmid, 0, -1);
+            if (rc) return rc;
+            A2.kmax = gm.kmax; A2.waves = gm.waves; A2.wave_doubles = gm.wave_doubles;
+            rc = launch_method(method, A2, gm, s, true);
+            if (rc) return rc;
+            HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 1), s));
+            HIPCHK(hipMemsetAsync(sb.xq, 0, sizeof(int) * 8, s));
+            hipLaunchKernelGGL(requeue_overflow_kernel, dim3(nb), dim3(256), 0, s, nvox, fa_index, status, sb);
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
+            hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
+            HIPCHK(hipGetLastError());
+        }
         A2.kmax = g2.kmax; A2.waves = g2.waves; A2.wave_doubles = g2.wave_doubles;
         rc = launch_method(method, A2, g2, s, true);
         if (rc) return rc;
