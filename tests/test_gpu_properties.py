@@ -238,10 +238,11 @@ def test_odd_shapes_vs_oracle(pkg, nte, nt2):
     assert np.allclose(resid.cpu().numpy(), rs, rtol=1e-6, atol=1e-9 * np.abs(rs).max())
 
 
-@pytest.mark.parametrize("nte,nt2", [(8, 12), (15, 20), (24, 40), (32, 64), (47, 65), (63, 128)])
+@pytest.mark.parametrize("nte,nt2", [(8, 12), (15, 20), (24, 40), (29, 33), (30, 40), (32, 64), (47, 65), (63, 128)])
 def test_gcv_and_bayes_objectives_at_odd_shapes(pkg, nte, nt2):
     # the direct GCV trace (MFMA Gram tiles, tridiagonalisation, bisection) and the blocked MFMA Cholesky of BayesReg at tile
-    # edges: m + 1 = 9 (one partial tile), 16 (exactly one), 25, 33, 48 (exactly three), 64 (four full tiles, every lane a row);
+    # edges: m + 1 = 9 (one partial tile), 16 (exactly one), 25, 33, 48 (exactly three), 64 (four full tiles, every lane a row); nTE = 29, 30, 47
+    # leave 3, 2, 1 zero-padded columns in the four-wide sweeps over C (only C = Dr Dr^T is in LDS since round 3);
     # nT2 = 12 ... 128 (one partial tile ... eight tiles, two bins per lane).  Objective values on a fixed lambda grid against the oracle.
     import torch
     from oracle import oracle
@@ -271,3 +272,33 @@ def test_gcv_and_bayes_objectives_at_odd_shapes(pkg, nte, nt2):
     well = lams >= 1e-2
     ok = np.isfinite(ref[:, well])
     assert np.allclose(got[:, well][ok], ref[:, well][ok], rtol=1e-8, atol=1e-8), (nte, nt2, np.abs(got[:, well][ok] - ref[:, well][ok]).max())
+
+
+@pytest.mark.parametrize("nte,nt2", [(32, 65), (40, 96), (48, 100), (63, 127), (63, 128)])
+def test_bayesreg_fit_at_two_bins_per_lane_odd_shapes(pkg, nte, nt2):
+    # BayesReg with nT2 > 64 builds its n x n factor one 16-row panel at a time (chol_lean: panel in LDS, finished block rows in the
+    # wave's global scratch) and runs its solver under the capacity scheme: partial last tiles (65 = 4 x 16 + 1, 100, 127), exactly
+    # eight tiles (128), a capacity (largest that lets eight waves share the LDS) below and above 64.  Whole fits against the oracle:
+    # BayesReg/I agrees to ~1e-9 except for the odd Brent tie (5e-4 of the voxels at 32 x 60, tests/test_tail_parity.py).
+    import torch
+    from oracle import oracle
+    oracle.build()
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty("I", T2s)
+    nvox = 256
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=7000 + nte * 131 + nt2, device="cuda")
+    D = np.ascontiguousarray(np.transpose(plan.get_dictionary(), (2, 0, 1)))
+    L = oracle.penalty(nt2, "I", T2s)
+    d = data.cpu().numpy(); ones = np.ones(nvox)
+    out = plan.fit("BayesReg", data, want_lambda=True)
+    fs, sg, rg, so = oracle.fit_batch("BayesReg", D, L, d, np.zeros(nvox), ones, nthreads=8)
+    got = out["fsol"].cpu().numpy()
+    e = np.max(np.abs(got - fs), axis=1) / np.max(np.abs(fs), axis=1)
+    lam = out["lam"].cpu().numpy()
+    print("MEASURED bayes odd %dx%d n_over=%d of %d median %.2e max %.2e" % (nte, nt2, int((e >= 1e-5).sum()), nvox, np.median(e), e.max()))
+    st = out["status"].cpu().numpy()
+    assert (st & 1).all() and not (st & (8 | 32)).any(), st[(st & 40) != 0][:4]  # fitted; no Cholesky failure; MET2_ST_KOVERFLOW never survives the clean-up pass
+    assert np.isfinite(got).all() and (got >= 0).all() and (lam > 0).all()
+    assert np.median(e) < 1e-7 and (e >= 1e-5).sum() <= 4, (nte, nt2, np.median(e), int((e >= 1e-5).sum()), e.max())
