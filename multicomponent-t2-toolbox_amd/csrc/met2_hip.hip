@@ -460,6 +460,13 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 #ifndef MET2_BAYES_WAVES
 #define MET2_BAYES_WAVES 12
 #endif
+#ifndef MET2_ONE_REFAC
+#define MET2_ONE_REFAC 2      // the GCV and BayesReg kernels at two bins per lane: 2 = the warm re-factorisation alone takes the one-slot
+                              // row-by-row form while k <= 64 (0: the blocked MFMA form always).  Their registers do not hold the one-slot
+                              // legs of the iteration as well (nnls_wave.hpp: MET2_ONE_SLOT), but this one routine they do: GCV of
+                              // configs[4] on 131 072 voxels 257.1 -> 244.8 ms (30 spilled VGPRs instead of 18), BayesReg at 48 x 120
+                              // 41.5 -> 39.9 ms (256 VGPRs, 4 spilled)
+#endif
 __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 {
     const int base = method >= 10 ? method - 10 : method;
@@ -595,8 +602,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, kmax = A.kmax;
     // one position slot while k <= 64 (nnls_wave.hpp: MET2_ONE_SLOT) in the two-bins-per-lane kernels that have the registers for a second
-    // code path: NNLS, T2SPARC, X2, L-curve (GCV at 255 VGPRs and BayesReg at 241 do not)
-    constexpr bool ONE = (NB == 2) && ((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE);
+    // code path: NNLS, T2SPARC, X2, L-curve (ONE = 1); GCV and BayesReg take it for the re-factorisation only (ONE = 2)
+    constexpr int ONE = (NB == 2) ? (((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE) ? 1 : MET2_ONE_REFAC) : 0;
     const int tri = A.wave_doubles;
     double *sR = smem + (size_t)wave * tri;             // every wave's region starts 16-byte aligned
 
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double *cholG = (NB == 2 && A.chol) ? A.chol + (size_t)(blockIdx.x * (unsigned)A.waves + (unsigned)wave) * (size_t)A.chol_stride : nullptr;
                 double lam = fminbound_dev([&](double x) {
                     if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
-                    nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
                     BayesTable tab{nullptr, 0.0};
                     if (A.btab && ev < A.nbtab) {                  // still on the abscissae every voxel shares?  (a rounding-level match: the table's
                         const double tl = A.blam[ev];              //  lambda_j is formed on the host, and B + lambda K does not care about an ulp)
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
-                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             } else if (METHOD == MET2_GCV) {
                 // algorithms.py:276-283
@@ -802,12 +809,12 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
                 double lam = fminbound_dev([&](double x) {
                     if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
-                    nnls_solve_warm<NB>(S, bd, st, x, true, lane);
+                    nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
                     return gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
                 }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
-                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB>(S, bd, st, lam, true, lane);
+                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
             }
             if (METHOD >= 10) {

@@ -761,17 +761,17 @@ __device__ __forceinline__ bool iterate_leg(const WaveShared &S, const Band<NB> 
 
 #ifndef MET2_ONE_SLOT
 #define MET2_ONE_SLOT 1       // 1: at two bins per lane the position-indexed work runs on one register slot while k <= 64 (0: always two),
-                              //    in the kernels that ask for it (template argument ONE: those with registers to spare -- the GCV kernel at
-                              //    255 VGPRs spilled and lost 31 % with both code paths in it)
+                              //    in the kernels that ask for it (template argument ONE = 1: those with registers to spare -- the GCV kernel at
+                              //    255 VGPRs spilled and lost 31 % with both code paths in it; ONE = 2: the re-factorisation only)
 #endif
 // Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
 // warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
 // (P, lam) -- start with the secondary loop instead of from the empty set.
-template <int NB, bool ONE = false>
+template <int NB, int ONE = 0>
 __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
                                              bool warm = false)
 {
-    if constexpr (NB == 2 && ONE && MET2_ONE_SLOT) {
+    if constexpr (NB == 2 && ONE == 1 && MET2_ONE_SLOT) {
         int iter = 0, outer = 0;
         if (st.k <= 63 && iterate_leg<NB, 1>(S, bd, st, lam, mrows, lane, warm, iter, outer)) return;
         (void)iterate_leg<NB, NB>(S, bd, st, lam, mrows, lane, warm, iter, outer);
@@ -1195,7 +1195,7 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
 #ifndef MET2_REFACTOR_BLOCKED_FROM
 #define MET2_REFACTOR_BLOCKED_FROM 2        // bins per lane from which the blocked form is used
 #endif
-template <int NB, bool ONE = false>
+template <int NB, int ONE = 0>
 __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
     if (NB == 2 && ONE && MET2_ONE_SLOT && MET2_ONE_SLOT_REFACTOR && st.k <= 64) return refactor_rowwise<NB, 1>(S, bd, st, lam, lane);   // k <= 64: one position slot, row by row
@@ -1205,7 +1205,7 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
 }
 
 // cold-start solve; on return st.x is the solution
-template <int NB, bool ONE = false>
+template <int NB, int ONE = 0>
 __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
     nnls_reset<NB>(st);
@@ -1273,7 +1273,7 @@ __device__ __forceinline__ void reorder_by_x(const WaveShared &S, NnlsState<NB> 
 // rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
 // strictly convex problem does not depend on the starting point, so this returns the same x as the
 // cold start up to rounding; it only skips the passes that would rebuild the same passive set.
-template <int NB, bool ONE = false>
+template <int NB, int ONE = 0>
 __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
     const int kold = st.k;

@@ -778,23 +778,27 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     const double eprev = (lane > 0 && lane < n) ? eg : 0.0;
     const double e2prev = eprev * eprev;                               // lane j: (d_j, e_{j-1}^2)
     const double bound = fmax(wave_max((lane < n) ? fabs(dj) + fabs(ej) + fabs(eprev) : 0.0), 1e-300);
+    const double dmax = fmax(wave_max((lane < n) ? dj : 0.0), bound * 1e-18);      // the largest eigenvalue is at least the largest diagonal entry (Rayleigh)
     __builtin_amdgcn_wave_barrier();
     MET2_GCV_LAP(9);
     // ---- 3. the eigenvalues that survive the cut, by multisection on the bit patterns.
     // Only eigenvalues above eps k mu_max enter the trace (np.linalg.lstsq drops the rest) -- 7 to 16 of the 33 / 49 -- so the lanes are
     // spent on those instead of one lane per eigenvalue:
-    //   A. the largest eigenvalue: all 64 lanes x 2 shifts = a 129-section per Sturm pass (7 bits), 4 passes;
+    //   A. the largest eigenvalue, coarsely: it lies between the largest diagonal entry and the Gershgorin bound (at most 3 x apart
+    //      for a positive semi-definite T: e_i^2 <= d_i d_{i+1}); all 64 lanes x 2 shifts = a 129-section per Sturm pass, 2 passes
+    //      -> 1e-4 relative, enough for the cut eps k mu_max (the reference's own sigma_max carries more noise than that at the cut);
     //   B. r = number of eigenvalues above the cut: one pass;
-    //   C. the r largest: a group of G = 64 / 16 = 4 lanes x 2 shifts per eigenvalue = a 9-section per pass (3.17 bits), 9 passes;
-    //      more than 16 survivors (not seen on the reference's recipe): the one-lane-per-eigenvalue quaternary search of round 2.
-    // 14 passes of 2 chains instead of 14 of 3, and the eigenvalues under the cut are never refined.
+    //   C. the r largest, mu_max among them: a group of G = 64 / 16 = 4 lanes x 2 shifts per eigenvalue = a 9-section per pass
+    //      (3.17 bits), 9 passes; more than 16 survivors (not seen on the reference's recipe): the one-lane-per-eigenvalue
+    //      quaternary search of round 2.
+    // 12 passes of 2 chains instead of 14 of 3, and the eigenvalues under the cut are never refined.
     // the Gershgorin bound is at most sqrt(n) mu_max, so bound * 1e-18 lies below any cut eps k mu_max
     double mu;
     int r_keep;
     {
-        unsigned long long lo = (unsigned long long)__double_as_longlong(bound * 1e-18);
+        unsigned long long lo = (unsigned long long)__double_as_longlong(dmax * 0.9999999);
         unsigned long long hi = (unsigned long long)__double_as_longlong(bound * 1.0000001);
-        for (int step = 0; step < 4; ++step) {                       // A: 129^4 = 2.8e8 > 2^28 (60 octaves -> 2.4e-7 relative)
+        for (int step = 0; step < 2; ++step) {                       // A: 129^2 sections of at most log2(3) octaves -> 7e-5 relative
             const unsigned long long q = (hi - lo) / 129ull;
             const unsigned long long m1 = lo + (unsigned long long)(2 * lane + 1) * q, m2 = m1 + q;
             const double xs[2] = {__longlong_as_double((long long)m1), __longlong_as_double((long long)m2)};
@@ -817,9 +821,11 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
             r_keep = n - c[0];
         }
         if (r_keep <= 16) {                                                          // C
+            // (groups of 8 or 16 lanes when at most 8 or 4 eigenvalues survive -- 7 passes of a 17-section, 6 of a 33-section --
+            //  measured the same as the fixed groups of four: 234.2 against 232.4 ms on configs[4]'s 131 072 voxels)
             const int e = lane >> 2, sidx = lane & 3;
             const int want = n - e;                                                  // the (e+1)-th largest: at least `want` eigenvalues below the shift
-            unsigned long long glo = (unsigned long long)__double_as_longlong(cut_ * 0.9999999);
+            unsigned long long glo = (e == 0) ? lo : (unsigned long long)__double_as_longlong(cut_ * 0.9999999);   // group 0: mu_max, inside A's bracket
             unsigned long long ghi = hi;
             for (int step = 0; step < 9; ++step) {                                   // 9^9 = 3.9e8 > 2^28
                 const unsigned long long q = (ghi - glo) / 9ull;
@@ -838,7 +844,6 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
             // lane i < r takes eigenvalue i (its group's result sits in lanes 4 i .. 4 i + 3)
             const double mug = __longlong_as_double((long long)ghi);
             mu = gather(mug, (4 * lane) & 63);
-            mu = (lane == 0) ? mumax_ : mu;
             mu = (lane < r_keep) ? mu : 0.0;                                         // under the cut: dropped below (mu > cut fails)
         } else {
             unsigned long long lo2 = (unsigned long long)__double_as_longlong(bound * 1e-18);
