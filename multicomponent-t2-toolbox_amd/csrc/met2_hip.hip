@@ -461,11 +461,12 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 #define MET2_BAYES_WAVES 12
 #endif
 #ifndef MET2_ONE_REFAC
-#define MET2_ONE_REFAC 2      // the GCV and BayesReg kernels at two bins per lane: 2 = the warm re-factorisation alone takes the one-slot
-                              // row-by-row form while k <= 64 (0: the blocked MFMA form always).  Their registers do not hold the one-slot
-                              // legs of the iteration as well (nnls_wave.hpp: MET2_ONE_SLOT), but this one routine they do: GCV of
-                              // configs[4] on 131 072 voxels 257.1 -> 244.8 ms (30 spilled VGPRs instead of 18), BayesReg at 48 x 120
-                              // 41.5 -> 39.9 ms (256 VGPRs, 4 spilled)
+#define MET2_ONE_REFAC 3      // the GCV and BayesReg kernels at two bins per lane, while k <= 64: 2 = the warm re-factorisation takes the one-slot
+                              // row-by-row form, 3 = the back substitutions run on one slot too (0: two slots, blocked MFMA re-factorisation).
+                              // Their registers do not hold the one-slot legs of the whole iteration (nnls_wave.hpp: MET2_ONE_SLOT), but these
+                              // two routines they do.  GCV of configs[4] on 131 072 voxels: 257.1 (0) -> 244.8 (2) -> 222.7 ms (3; with the
+                              // removals and appends on one slot as well: 224.6 ms at 103 spilled VGPRs); BayesReg at 48 x 120 on 32 768:
+                              // 41.5 -> 39.9 -> 38.2 ms (the fourth level: 71 ms).  profiles/r03_other_ab.txt
 #endif
 __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 {
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, kmax = A.kmax;
     // one position slot while k <= 64 (nnls_wave.hpp: MET2_ONE_SLOT) in the two-bins-per-lane kernels that have the registers for a second
-    // code path: NNLS, T2SPARC, X2, L-curve (ONE = 1); GCV and BayesReg take it for the re-factorisation only (ONE = 2)
+    // code path: NNLS, T2SPARC, X2, L-curve (ONE = 1); GCV and BayesReg take it for the re-factorisation and the back substitution (ONE = 3)
     constexpr int ONE = (NB == 2) ? (((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE) ? 1 : MET2_ONE_REFAC) : 0;
     const int tri = A.wave_doubles;
     double *sR = smem + (size_t)wave * tri;             // every wave's region starts 16-byte aligned

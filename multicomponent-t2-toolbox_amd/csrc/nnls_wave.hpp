@@ -557,7 +557,7 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
 // Lawson-Hanson's secondary loop: from a feasible x and a factor consistent with (P, lambda), move to
 // the solution of the passive sub-problem, dropping variables that hit zero on the way.
 // Returns false when the iteration cap is reached.
-template <int NB, int NP = NB>
+template <int NB, int NP = NB, bool BS1 = false>
 __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &st, int &iter, int itmax, int lane)
 {
     for (;;) {
@@ -565,7 +565,8 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
         double z[NB], xp[NB], zb[NB], ratio[NB];
         bool neg[NB];
         if (MET2_DOUBLE == 4) { back_subst<NB, NP>(S, st, lane, z); asm volatile("" :: "v"(z[0])); }
-        back_subst<NB, NP>(S, st, lane, z);                  // position-indexed
+        if (BS1 && NP == 2 && st.k <= 64) back_subst<NB, 1>(S, st, lane, z);     // (ONE = 3: the substitution on one slot inside the two-slot iteration)
+        else back_subst<NB, NP>(S, st, lane, z);             // position-indexed
         bool any = false;
 #pragma unroll
         for (int b = NP; b < NB; ++b) { neg[b] = false; ratio[b] = 2.0; xp[b] = 0.0; }
@@ -626,14 +627,14 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
 }
 
 // The passive-set iteration on NB position slots (the general form).
-template <int NB>
+template <int NB, bool BS1 = false>
 __device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
                                                    bool warm)
 {
     const int n = S.n, itmax = 3 * n;
     int iter = 0;
     MET2_CYC_BEGIN(c_in0);
-    if (warm && st.k > 0 && !nnls_inner<NB>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
+    if (warm && st.k > 0 && !nnls_inner<NB, NB, BS1>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
     MET2_CYC_END(2, c_in0);
     for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows) break;
@@ -680,7 +681,7 @@ __device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Ba
         MET2_CYC_ADD(14, 1);
         if (!accepted) break;
         MET2_CYC_BEGIN(c_in);
-        const bool inner_ok = nnls_inner<NB>(S, st, iter, itmax, lane);
+        const bool inner_ok = nnls_inner<NB, NB, BS1>(S, st, iter, itmax, lane);
         MET2_CYC_END(2, c_in);
         MET2_CYC_ADD(15, 1);
         if (!inner_ok) { st.itmax_hit |= 1; break; }
@@ -762,7 +763,8 @@ __device__ __forceinline__ bool iterate_leg(const WaveShared &S, const Band<NB> 
 #ifndef MET2_ONE_SLOT
 #define MET2_ONE_SLOT 1       // 1: at two bins per lane the position-indexed work runs on one register slot while k <= 64 (0: always two),
                               //    in the kernels that ask for it (template argument ONE = 1: those with registers to spare -- the GCV kernel at
-                              //    255 VGPRs spilled and lost 31 % with both code paths in it; ONE = 2: the re-factorisation only)
+                              //    255 VGPRs spilled and lost 31 % with both code paths in it; ONE = 2: the re-factorisation only; ONE = 3: the re-factorisation
+                              //    and the back substitution, inside the two-slot iteration)
 #endif
 // Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
 // warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
@@ -776,7 +778,7 @@ __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB>
         if (st.k <= 63 && iterate_leg<NB, 1>(S, bd, st, lam, mrows, lane, warm, iter, outer)) return;
         (void)iterate_leg<NB, NB>(S, bd, st, lam, mrows, lane, warm, iter, outer);
     } else
-        nnls_iterate_plain<NB>(S, bd, st, lam, mrows, lane, warm);
+        nnls_iterate_plain<NB, (NB == 2 && ONE == 3)>(S, bd, st, lam, mrows, lane, warm);
 }
 
 template <int NB>
