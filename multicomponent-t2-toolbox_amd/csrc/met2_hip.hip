@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64) void seed_kernel(SeedArgs A)
     WaveShared S;
     S.R = smem; S.n = n; S.m = m; S.kmax = n; S.rcap = col_base(n); S.K = A.Kd; S.kband = A.kband;
     S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n; S.DtG = S.Dt;
-    S.bstride = n; S.dstride = n; S.dtstride = m; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.bstride = n; S.dstride = n; S.dtstride = m; S.buffer_rows = true; S.reorder = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
     Band<NB> bd;
     load_band<NB>(bd, A.kband, A.lband, lane);
     // canonical spectrum on the (log-spaced) T2 axis: 15 % at 13 % of the axis, 85 % at 39 % (20 ms and 80 ms on 10..2000 ms)
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void bayes_table_kernel(BayesTabArgs A)
     WaveShared S;
     S.R = smem; S.n = n; S.m = A.m; S.kmax = n; S.rcap = col_base(n); S.K = A.Kd; S.kband = A.kband;
     S.B = A.Bfa + (size_t)fa * n * n; S.D = nullptr; S.Dt = nullptr; S.DtG = nullptr;
-    S.bstride = n; S.dstride = n; S.dtstride = A.m; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.bstride = n; S.dstride = n; S.dtstride = A.m; S.buffer_rows = true; S.reorder = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
     Band<NB> bd;
     load_band<NB>(bd, A.kband, A.lband, lane);
     double det_u;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     double *sR = smem + (size_t)wave * tri;             // every wave's region starts 16-byte aligned
 
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = true; S.reorder = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
     S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n;
     Band<NB> bd;
     load_band<NB>(bd, A.kband, A.lband, lane);
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
     const int n = A.n, m = A.m;
     double *sR = smem + (size_t)wave * A.wave_doubles;
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = false; S.have_bdiag = true; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.R = sR; S.n = n; S.m = m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = nullptr; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = false; S.reorder = false; S.have_bdiag = true; S.bdiag[0] = S.bdiag[1] = 0.0;
     S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n;
     Band<NB> bd;
 #pragma unroll

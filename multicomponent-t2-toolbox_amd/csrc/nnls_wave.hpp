@@ -73,6 +73,8 @@ struct WaveShared {
     int rcap;           // doubles available at R
     bool have_bdiag;    // bdiag holds B[j][j] of the lane's bins (the FA walk sets it once per flip angle: its refactorisations are too
     double bdiag[2];    // short -- k ~ 8 -- to hide the latency of loading the diagonal inside refactor())
+    bool reorder;       // warm starts re-order the pivots by descending x (reorder_by_x) -- off in the FA walk, where neighbouring flip angles
+                        // keep the passive set and the ranking is pure overhead (FA walk of configs[4] on 131 072 voxels: 45.0 -> 42.1 ms)
     bool buffer_rows;   // row loads of the global matrices as raw buffer loads (fit kernels); false: plain global loads (the FA walk, whose
                         // 19 MB of dictionaries at 48 x 120 missed L2 1.7x more often through the buffer path: 57 -> 66 ms per 131 k voxels)
 };
@@ -1281,7 +1283,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     const int kold = st.k;
     if (kold == 0) { nnls_solve<NB, ONE>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
-    if (NB >= MET2_REORDER && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
+    if (NB >= MET2_REORDER && S.reorder && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
     if (!refactor<NB, ONE>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
         int ordold[NB];
