@@ -155,3 +155,25 @@ def test_s2_vs_oracle_maps(pkg, gS2, plan91):
         assert np.max(np.abs(maps[i][ok] - mo[name][ok])) / max(1.0, np.max(np.abs(mo[name]))) < TOL, name
     m2 = plan91.metrics(out["fsol"]).cpu().numpy()
     assert np.allclose(m2, maps, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("meth,pen", [("X2", "L2"), ("L_curve", "L1"), ("GCV", "L2"), ("BayesReg", "InvT2")])
+def test_capacity_ladder_leaves_no_voxel_behind_s2(pkg, gS2, meth, pen):
+    # At two bins per lane the first pass runs at the capacity that lets eight waves share the LDS (71 of 120 bins); voxels whose
+    # passive set outgrows it leave the pass at once and are solved again by the clean-up passes (GCV: 116, then 120; the others:
+    # 120).  8 192 synthetic voxels are enough for a few hundred to take that route: none may keep MET2_ST_KOVERFLOW, every one must
+    # be a KKT point of its own lambda, and the result must not depend on the voxel's place in the list (the passes re-sort it).
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    g = gS2
+    plan = _single(pkg, g, pen)
+    nvox = 8192
+    data, _, _ = synth.make_voxels(nvox, nte=int(g["nte"]), seed=4242, device="cuda")
+    out = plan.fit(meth, data, want_lambda=True)
+    st = out["status"].cpu().numpy()
+    assert (st & 1).all() and not (st & 32).any(), np.unique(st)
+    f = out["fsol"].cpu().numpy()
+    assert np.isfinite(f).all() and (f >= 0).all()
+    perm = torch.randperm(nvox, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    out2 = plan.fit(meth, data[perm].contiguous(), want_lambda=True)
+    assert torch.equal(out2["fsol"], out["fsol"][perm]) and torch.equal(out2["lam"], out["lam"][perm])
