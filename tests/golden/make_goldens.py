@@ -639,14 +639,13 @@ def _x2_reference(D, M, L, procs=7, chunk=64, tag=""):
     return F, Lm, Ke
 
 
-def gen_tail_x2(nvox, seed, procs=7):
+def gen_tail_x2(nvox, seed, procs=7, nte=32, npc=60, name="golden_tail_X2.npz"):
     """configs[1]'s method (X2/L2, 32 x 60, FA 150) on enough voxels through the reference's nnls_x2 (algorithms.py:211-233) that
     a 6e-5 tail is countable.  To keep the file small the signals are rounded to float32 BEFORE they go through the reference
     (so the stored float32 array IS the input, exactly) and the reference's spectra are stored as float32 (relative rounding
     6e-8, far inside the 1e-5 tolerance); lambda, k_est and the MWF of the float64 spectra stay float64."""
     from epg.epg import create_Dic_3D, epg_signal
     from motor.motor_recon_met2_real_data import create_Laplacian_matrix
-    nte, npc = 32, 60
     rng = np.random.default_rng(seed)
     T2s = t2_grid(npc); T1s = 1000.0 * np.ones_like(T2s)
     D = np.ascontiguousarray(create_Dic_3D(npc, T2s, T1s, nte, 10.0, np.array([150.0]), 3000.0)[:, :, 0])
@@ -654,11 +653,11 @@ def gen_tail_x2(nvox, seed, procs=7):
     data = data.astype(np.float32).astype(np.float64)
     M = data / data[:, :1]
     L = penalties(npc, T2s, create_Laplacian_matrix)["L2"]
-    F, Lm, Ke = _x2_reference(D, M, L, procs=procs, tag="tail X2/L2")
+    F, Lm, Ke = _x2_reference(D, M, L, procs=procs, tag="tail X2/L2 %dx%d" % (nte, npc))
     mwf = F[:, T2s <= 40.0].sum(axis=1) / (F.sum(axis=1) + 1e-16)
-    np.savez_compressed(os.path.join(HERE, "golden_tail_X2.npz"), T2s=T2s, T1s=T1s, TR=3000.0, tau=10.0, nte=nte, npc=npc, D150=D,
+    np.savez_compressed(os.path.join(HERE, name), T2s=T2s, T1s=T1s, TR=3000.0, tau=10.0, nte=nte, npc=npc, D150=D,
                         data=data.astype(np.float32), X2_L2_f=F.astype(np.float32), X2_L2_lam=Lm, X2_L2_aux=Ke, X2_L2_mwf=mwf)
-    print("wrote golden_tail_X2.npz (%d voxels)" % nvox)
+    print("wrote %s (%d voxels)" % (name, nvox))
 
 
 def gen_x2_failset(path):
@@ -702,6 +701,8 @@ def main():
                                       ("BayesReg", "InvT2", 4096), ("BayesReg", "I", 1024), ("GCV", "L2", 4096)], 20260121)
     if "tailX2" in which:        # ~8 minutes on 7 processes
         gen_tail_x2(65536, 20260123)
+    if "tailX2S2" in which:      # the same at config 5's shape (48 x 120: the two-bins-per-lane kernels), 8 192 voxels; ~10 minutes on 7 processes
+        gen_tail_x2(8192, 20260124, nte=48, npc=120, name="golden_tail_X2_S2.npz")
     if "x2fail" in which:        # needs gpurun_out/fail_x2l2.npz (bench.py --config 1 --dump-fail on the GPU box)
         gen_x2_failset(os.environ.get("MET2_FAILSET", os.path.join(HERE, "..", "..", "gpurun_out", "fail_x2l2.npz")))
     if "tailS2" in which:

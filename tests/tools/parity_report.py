@@ -110,16 +110,19 @@ def main():
             print(json.dumps(row), flush=True)
     # ---- the 65 536-voxel X2/L2 fixture (configs[1]'s method; make_goldens.py tailX2: inputs float32-representable, reference spectra
     #      stored as float32) and the reference run on the voxels where HIP and oracle disagree (make_goldens.py x2fail)
-    path = os.path.join(GOLDEN, "golden_tail_X2.npz")
-    if os.path.exists(path):
+    #      (make_goldens.py tailX2S2: the same at 48 x 120, 8 192 voxels -- the two-bins-per-lane kernels)
+    for shape, fname in (("X2tail", "golden_tail_X2.npz"), ("X2tailS2", "golden_tail_X2_S2.npz")):
+        path = os.path.join(GOLDEN, fname)
+        if not os.path.exists(path):
+            continue
         g0 = np.load(path)
         g = {k: g0[k] for k in g0.files}
         g["data"] = g0["data"].astype(np.float64); g["lambda_grid"] = np.zeros(50); fref = g0["X2_L2_f"].astype(np.float64)
         n = fref.shape[0]
-        doc["fixtures"]["X2tail"] = {"file": os.path.relpath(path, ROOT), "nte": 32, "npc": 60, "voxels": int(n),
-                                     "note": "p50/p99 of ~3e-8 are the float32 storage of the reference spectra"}
+        doc["fixtures"][shape] = {"file": os.path.relpath(path, ROOT), "nte": int(g0["nte"]), "npc": int(g0["npc"]), "voxels": int(n),
+                                  "note": "p50/p99 of ~3e-8 are the float32 storage of the reference spectra"}
         fo, lo = oracle_fit(oracle, g, "X2", "L2", n)
-        row = {"shape": "X2tail", "method": "X2", "penalty": "L2", "reference_vs_oracle": stats(fo, fref, g["T2s"], lo, g["X2_L2_lam"])}
+        row = {"shape": shape, "method": "X2", "penalty": "L2", "reference_vs_oracle": stats(fo, fref, g["T2s"], lo, g["X2_L2_lam"])}
         if gpu:
             fh, lh = hip_fit(pkg, torch, g, "X2", "L2", n)
             row["reference_vs_hip"] = stats(fh, fref, g["T2s"], lh, g["X2_L2_lam"])
