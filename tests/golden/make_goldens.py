@@ -705,6 +705,8 @@ def main():
         gen_tail_x2(8192, 20260124, nte=48, npc=120, name="golden_tail_X2_S2.npz")
     if "x2fail" in which:        # needs gpurun_out/fail_x2l2.npz (bench.py --config 1 --dump-fail on the GPU box)
         gen_x2_failset(os.environ.get("MET2_FAILSET", os.path.join(HERE, "..", "..", "gpurun_out", "fail_x2l2.npz")))
+    if "tailS2b" in which:       # BayesReg/I at 48 x 120 on 2 048 voxels (the method with rounding-level parity: pins the panel Cholesky); ~3 minutes
+        gen_tail("S2b", 48, 120, 2048, [("BayesReg", "I", 2048)], 20260125)
     if "tailS2" in which:
         gen_tail("S2", 48, 120, 512, [("X2", "L2", 512), ("L_curve", "L1", 512), ("BayesReg", "InvT2", 512), ("GCV", "L2", 512)],
                  20260122)
