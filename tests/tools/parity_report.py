@@ -26,7 +26,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 PKG = "multicomponent-t2-toolbox_amd"
 
 PAIRS = {"S1": [("NNLS", "I"), ("X2", "L2"), ("X2", "I"), ("L_curve", "L1"), ("BayesReg", "InvT2"), ("BayesReg", "I"), ("GCV", "L2")],
-         "S2": [("X2", "L2"), ("L_curve", "L1"), ("BayesReg", "InvT2"), ("GCV", "L2")]}
+         "S2": [("X2", "L2"), ("L_curve", "L1"), ("BayesReg", "InvT2"), ("GCV", "L2")],
+         "S2b": [("BayesReg", "I")]}
 
 
 def rel_rows(a, b):
