@@ -69,10 +69,10 @@ def host_cores():
     return int(os.environ.get("MET2_CPU_THREADS", n))
 
 
-def source_sha():
+def source_sha(files=("met2_hip.hip", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp")):
     """Digest of the kernel sources: counter files under profiles/ are only quoted while they describe this build."""
     h = hashlib.sha256()
-    for f in ("met2_hip.hip", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp"):
+    for f in files:
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -216,8 +216,105 @@ def end_to_end(plan, pkg, method, data, brute, chunk_vox=262144, reps=3):
                         % ("brute-force FA -> " if brute else "", chunk_vox)}
 
 
+def tv_main(args, rank, local_rank, world):
+    """--workload tv: the driver's TV step (motor:293-304) on a spatially organised phantom of the config's shape; one step = every echo
+    volume through estimate_sigma + denoise_tv_chambolle (weight 2 sigma, eps 2e-4, at most 200 iterations), device-resident in and
+    out.  The stencil kernel is HBM-bound: `roofline` prices its 56 algorithmic bytes per (voxel, echo) and iteration."""
+    import ctypes as C
+    import torch.distributed as dist
+    synth = importlib.import_module(PKG + ".synth")
+    tv = importlib.import_module(PKG + ".tv")
+    lib = importlib.import_module(PKG + "._lib")
+    cfg = CONFIGS[args.config]
+    dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else cfg["dims"]
+    nte = args.nte or cfg["nte"]
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    vol, _ = synth.make_phantom(dims, nte=nte, seed=20260110 + rank, device=dev)
+    nvox = int(np.prod(dims))
+
+    def step():
+        return tv.tv_chambolle(vol, return_info=True)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    iter_ms = []; launches = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, sig, its = step()
+        ms = C.c_double(); nl = C.c_int32()
+        lib.check(lib.lib().met2_tv_last_timing(C.byref(ms), C.byref(nl)))
+        iter_ms.append(ms.value); launches.append(nl.value)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        it_sum = int(its.sum())
+        bytes_iter = 56.0 * nvox * it_sum                     # read p (3) + f (1), write p (3) per active (voxel, echo) and iteration
+        ims = float(np.mean(iter_ms))
+        achieved = bytes_iter / (ims * 1e-3) / 1e9
+        traffic = None; pmc_note = "no counter file for this workload"
+        try:
+            ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json"))).get("tv_%dx%dx%dx%d" % (dims + (nte,)))
+            if ent is not None and ent.get("src_sha") == source_sha(("met2_tv.hip",)):
+                traffic = ent.get("hbm_bytes_per_launch")
+                pmc_note = "profiles/%s (tag %s)" % (ent.get("files"), ent.get("tag"))
+        except Exception:
+            pass
+        line = {"metric": "voxels/sec through the TV denoising step (motor:293-304), all %d echo volumes" % nte,
+                "value": world * nvox * args.steps / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": "TV denoising of a synthetic %dx%dx%d head phantom, nTE=%d (estimate_sigma + denoise_tv_chambolle, weight 2 sigma, "
+                                       "eps 2e-4, <= 200 iterations); not a BASELINE config" % (dims + (nte,)),
+                           "voxels_per_gpu": nvox, "ranks_seen": world, "iterations_per_echo": its.tolist(),
+                           "sigma_per_echo_first_last": [float(sig[0]), float(sig[-1])], "iterations_enqueued": int(np.mean(launches)),
+                           "sharding": "one volume per rank, no collective" if world > 1 else "single GPU"},
+                "roofline": {"bound": "hbm", "kernel": "tv_iter_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "counters": pmc_note,
+                             "iteration_phase_ms": ims, "launches": int(np.mean(launches)), "active_echo_iterations": it_sum,
+                             "bytes_per_voxel_echo_iteration": 56,
+                             "note": "achieved = 56 B x voxels x (sum over echoes of the iterations each ran) / HIP-event time from the first to the last "
+                                     "Chambolle launch (tv_iter_kernel + the per-iteration tv_reduce_kernel, finished echoes' launches included)"}}
+        if not args.no_cpu_baseline:
+            from oracle import tv_oracle
+            host = vol.cpu().numpy()
+            t1 = time.time(); ne = 0; o0 = None; n0 = 0; s0 = 0.0; its_cpu = []
+            while ne < nte and time.time() - t1 < args.cpu_seconds:          # whole echo volumes until the time budget is used
+                v = np.ascontiguousarray(host[..., ne])
+                sg = tv_oracle.estimate_sigma(v)
+                o, n = tv_oracle.denoise_tv_chambolle(v, 2.0 * sg, return_iters=True)
+                if ne == 0:
+                    o0, n0, s0 = o, n, sg
+                its_cpu.append(n); ne += 1
+            d1 = time.time() - t1
+            line["cpu_baseline"] = {"value": nvox * ne / d1 / nte, "unit": "voxels/s", "cores": 1, "kind": "port",
+                                    "sample": "echo volumes 0..%d of the same phantom through the numpy restatement (oracle/tv_oracle.py), %d Chambolle iterations "
+                                              "in all, %.1f s; voxel-echoes/s divided by the %d echoes of the metric's unit" % (ne - 1, sum(its_cpu), d1, nte)}
+            g0 = out[..., 0].cpu().numpy()
+            line["parity"] = {"against": "numpy restatement of scikit-image's functions (PARITY UNPINNED: scikit-image is not in the image)",
+                              "echo": 0, "max_rel": float(np.max(np.abs(g0 - o0)) / np.max(np.abs(o0))), "iterations_hip_oracle": [int(its[0]), int(n0)],
+                              "sigma_rel": float(abs(sig[0] / s0 - 1.0))}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", type=str, default="fit", choices=["fit", "tv"],
+                    help="fit (default): BASELINE.json's metric; tv: the driver's TV denoising step on a phantom of the config's shape")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -261,6 +358,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if plumbing:
         sys.exit(plumbing_main(args, rank, world, mdist))
+    if args.workload == "tv":
+        if os.environ.get("MET2_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+        sys.exit(tv_main(args, rank, local_rank, world))
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MET2_ABI_VERSION 3
+#define MET2_ABI_VERSION 4
 
 /* reg_method of motor/motor_recon_met2_real_data.py:134-150 */
 enum met2_method {
@@ -50,7 +50,8 @@ enum met2_status {
     MET2_ST_NONFINITE = 4,     /* NaN/Inf in the voxel's echoes: outputs zero (reference: ValueError) */
     MET2_ST_CHOLFAIL = 8,      /* BayesReg: Cholesky of beta(B + lambda K) failed (reference: LinAlgError) */
     MET2_ST_BRENT_MAXFUN = 16, /* lambda search stopped on maxfun                                  */
-    MET2_ST_KOVERFLOW = 32     /* internal passive-set capacity exceeded (never with default build) */
+    MET2_ST_KOVERFLOW = 32     /* passive-set capacity of a pass exceeded: set only transiently -- the clean-up passes redo such
+                                  voxels at full capacity, so no voxel returned by met2_fit carries it */
 };
 
 enum met2_error {
@@ -213,6 +214,32 @@ int met2_smooth_separable(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
 int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t n_te, const double *data,
                const uint8_t *mask, double *out, void *stream);
 
+/* motor:293-304, TV denoising (denoise='TV'; the reference's example pipeline runs it, example_script_run_MET2_preproc_and_recon.sh:54):
+ *     for every echo volume:  sigma_est = mean(estimate_sigma(vol));  vol <- denoise_tv_chambolle(vol, weight = 2 sigma_est, eps = 2e-4,
+ *                                                                                                 max_num_iter = 200)
+ * (scikit-image's functions, restated from the published algorithms: Donoho-Johnstone's db2 median estimator and Chambolle's
+ * projection algorithm in 3-D).  ALL n_te echo volumes go through every step in the same launches; the stopping rule is applied
+ * on the device per echo, the host reads nothing per iteration.
+ * DEVICE pointers: data and out, both [nx][ny][nz][n_te] (echo_major = 0, the C-ordered array of the driver) or both [n_te][nz][ny][nx]
+ * (echo_major = 1: the memory order of the Fortran-ordered array nibabel hands the driver, motor:167-173); out may alias data.
+ * HOST: weight [n_te] = the `weight` of denoise_tv_chambolle per echo, or NULL: weight = weight_factor x the echo's estimated sigma
+ * (the reference: weight_factor = 2).  An echo whose weight is not a positive finite number is copied through (an all-zero volume
+ * has sigma = 0; scikit-image would return nan for it).
+ * eps, max_num_iter: the reference passes 2e-4 and 200.  poll_every: 0 = every iteration of max_num_iter is enqueued and the call
+ * returns without waiting (launches for echoes that have converged return at once); k > 0 = the host looks at the device's flags
+ * every k iterations and stops enqueueing when every echo has converged (the call then blocks until that point).
+ * DEVICE out, may be NULL: sigma [n_te] the estimated noise level per echo (nan if the echo holds a nan or inf -- the reference's
+ * finite check would raise), iters [n_te] int32 Chambolle iterations executed per echo.
+ * work: DEVICE scratch of met2_tv_work_bytes() bytes (7 working copies of the volume), or NULL: allocated and freed inside, which
+ * makes the call blocking.  n_te <= 127 for echo_major = 0. */
+int64_t met2_tv_work_bytes(int32_t nx, int32_t ny, int32_t nz, int32_t n_te, int32_t echo_major);
+int met2_tv_chambolle(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t n_te, const double *data, int32_t echo_major,
+                      const double *weight, double weight_factor, double eps, int32_t max_num_iter, int32_t poll_every, double *out,
+                      double *sigma, int32_t *iters, void *work, int64_t work_bytes, void *stream);
+/* For reports: HIP-event time (ms) from the first to the last Chambolle launch of the calling thread's most recent
+ * met2_tv_chambolle (blocks until they finished) and the number of iterations that were enqueued. */
+int met2_tv_last_timing(double *iter_ms, int32_t *launches);
+
 /* motor/motor_recon_met2_real_data_ROI.py:405-420, the reduction of the ROI mode: for every ROI the mean signal over its
  * voxels and the mean EPG kernel, each voxel contributing the dictionary slice of its own flip angle
  * (total_signal / nv, total_Kernel / nv).  `src` holds the dictionary the flip angles index; `dst` is a plan of the same
@@ -233,8 +260,9 @@ int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_
  * this plan, measured with HIP events on the launch stream (blocks until it finished). */
 int met2_plan_last_kernel_ms(met2_plan *plan, double *ms);
 /* NNLS/T2SPARC/X2/L-curve/GCV fits run in two passes: the solver kernel with a reduced passive-set capacity (the
- * largest that lets 16 waves share a CU's LDS, never below 0.6 n_t2: 50 at n_t2 = 60, 72 at 120 -- more resident waves
- * per CU), then the same kernel at full capacity for the voxels that hit the cap (~1 %).
+ * largest that lets 16 waves share a CU's LDS, never below 0.6 n_t2: 50 at n_t2 = 60; at two bins per lane the largest that
+ * lets the 8 waves those kernels are compiled for share it: 71 at n_t2 = 120 -- more resident waves per CU), then the same
+ * kernel at full capacity (GCV at two bins per lane: at capacity 116 first, then full) for the voxels that hit the cap (~1 %).
  * met2_plan_last_kernel_ms times the first (dominant) launch; this gives the second pass (requeue + launch),
  * 0 when there was none. */
 int met2_plan_last_second_pass_ms(met2_plan *plan, double *ms);

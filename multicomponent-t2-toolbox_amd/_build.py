@@ -6,8 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmet2_hip.so")
-SOURCES = ["met2_hip.hip"]
-HEADERS = ["wave_ops.hpp", "nnls_wave.hpp", "objectives.hpp", os.path.join("..", "..", "include", "met2_hip.h")]
+# one object per translation unit (compiled side by side, linked into ONE library): the solver kernels, and the TV denoiser
+SOURCES = ["met2_hip.hip", "met2_tv.hip"]
+HEADERS = ["abi_common.hpp", "wave_ops.hpp", "nnls_wave.hpp", "objectives.hpp", os.path.join("..", "..", "include", "met2_hip.h")]
 STAMP = LIB + ".flags"          # extra compile flags the library was built with (MET2_BUILD_DEFINES, e.g. -DMET2_CYCSTATS)
 # Machine LICM off: it hoists the materialisation of fp64 literals (erf/log coefficients of the BayesReg objective, 20 register
 # pairs) and per-lane address constants out of the voxel loop, runs out of registers and spills them to scratch -- BayesReg at
@@ -38,13 +39,40 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _object(src):
+    return os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+
+
+def _object_stale(src, flags):
+    obj = _object(src)
+    if not os.path.exists(obj) or not os.path.exists(obj + ".flags") or open(obj + ".flags").read().split() != flags:
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + CODEGEN + extra_flags() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = extra_flags()
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + CODEGEN + flags
+    jobs = []
+    for src in SOURCES:
+        if force or _object_stale(src, flags):
+            cmd = base + ["-c", os.path.join(CSRC, src), "-o", _object(src)]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((src, cmd, subprocess.Popen(cmd)))
+    for src, cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        with open(_object(src) + ".flags", "w") as f:
+            f.write(" ".join(flags))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_object(s) for s in SOURCES]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     with open(STAMP, "w") as f:
-        f.write(" ".join(extra_flags()))
+        f.write(" ".join(flags))
     return LIB

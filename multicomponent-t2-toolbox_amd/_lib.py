@@ -25,7 +25,7 @@ SYMBOLS = ["met2_default_options", "met2_abi_version", "met2_device_count", "met
            "met2_plan_destroy", "met2_plan_set_options", "met2_plan_get_options", "met2_plan_build_dictionary_epg", "met2_plan_set_dictionary", "met2_plan_get_dictionary",
            "met2_plan_set_penalty", "met2_plan_set_penalty_dense", "met2_plan_get_penalty", "met2_plan_set_lambda_grid",
            "met2_plan_set_t2_grid", "met2_fit", "met2_fit_strided", "met2_fit_enqueue_strided", "met2_plan_finish", "met2_fa_bruteforce", "met2_fa_bruteforce_strided", "met2_fa_spline_select",
-           "met2_fa_spline_select_strided", "met2_roi_reduce", "met2_nesma", "met2_smooth_separable", "met2_metrics", "met2_plan_last_kernel_ms", "met2_plan_last_second_pass_ms",
+           "met2_fa_spline_select_strided", "met2_roi_reduce", "met2_nesma", "met2_tv_work_bytes", "met2_tv_chambolle", "met2_tv_last_timing", "met2_smooth_separable", "met2_metrics", "met2_plan_last_kernel_ms", "met2_plan_last_second_pass_ms",
            "met2_plan_launch_info"]
 
 
@@ -61,6 +61,10 @@ def lib():
         L.met2_roi_reduce.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]
         L.met2_fa_spline_select.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, vp, C.c_int32, _dp, C.c_int32, vp, vp, vp, vp, vp]
         L.met2_nesma.argtypes = [C.c_int32] * 5 + [vp] * 4
+        L.met2_tv_work_bytes.argtypes = [C.c_int32] * 5
+        L.met2_tv_work_bytes.restype = C.c_int64
+        L.met2_tv_chambolle.argtypes = [C.c_int32] * 5 + [vp, C.c_int32, _dp, C.c_double, C.c_double, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int64, vp]
+        L.met2_tv_last_timing.argtypes = [_dp, C.POINTER(C.c_int32)]
         L.met2_smooth_separable.argtypes = [C.c_int32] * 6 + [_dp] + [vp] * 4
         L.met2_metrics.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
         L.met2_plan_last_kernel_ms.argtypes = [vp, _dp]

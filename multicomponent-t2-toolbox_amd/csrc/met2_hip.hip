@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/met2_hip.h"
+#include "abi_common.hpp"
 #include "nnls_wave.hpp"
 #include "objectives.hpp"
 
@@ -36,27 +37,7 @@ using namespace met2;
 // error plumbing
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
-// makes `dev` current for the duration of a C-ABI call and puts the caller's device back afterwards
-struct DevGuard {
-    int prev = -1;
-    hipError_t err;
-    explicit DevGuard(int dev)
-    {
-        err = hipGetDevice(&prev);
-        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev); else if (err == hipSuccess) prev = -1;
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-#define USE_DEVICE(dev)                                                                                \
-    DevGuard dev_guard_(dev);                                                                          \
-    if (dev_guard_.err != hipSuccess) return fail(MET2_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(dev_guard_.err))
-
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(MET2_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
+int met2::abi_fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 // ------------------------------------------------------------------------------------------
 // EPG dictionary  (epg/epg.py:64-153).  Lane k holds order k: Fp = F_k (lane 0: F_0),

@@ -50,7 +50,7 @@ def epg_table(nte, tau, T2, T1, alpha_deg):
 
 
 def make_voxels(nvox, nte=32, seed=20260102, fa_deg=150.0, fa_values=None, snr=(50.0, 150.0), te=10.0, TR=3000.0,
-                device="cuda", chunk=65536):
+                device="cuda", chunk=65536, params=None):
     """Returns (data [nvox,nte] float64 tensor on `device`, fa_index float64 tensor or None, truth dict).
     fa_deg: constant flip angle; or fa_values (array of the dictionary's FA grid) -> per-voxel FA drawn
     uniformly from that grid, fa_index = its index."""
@@ -62,6 +62,8 @@ def make_voxels(nvox, nte=32, seed=20260102, fa_deg=150.0, fa_values=None, snr=(
         "MWF": rng.uniform(0.05, 0.25, nvox), "T2m": rng.uniform(15.0, 35.0, nvox), "T2ie": rng.uniform(60.0, 90.0, nvox),
         "SNR": rng.uniform(snr[0], snr[1], nvox), "sm": rng.uniform(1.0, 3.0, nvox), "sie": rng.uniform(6.0, 12.0, nvox),
     }
+    if params is not None:                                           # spatially organised parameters (make_phantom)
+        par.update({k: np.asarray(v, dtype=np.float64).reshape(nvox) for k, v in params.items()})
     if fa_values is None:
         fa_idx = None
         fas = [float(fa_deg)]
@@ -95,3 +97,21 @@ def make_voxels(nvox, nte=32, seed=20260102, fa_deg=150.0, fa_values=None, snr=(
         data[s:e] = torch.sqrt((S + n1) ** 2 + n2 ** 2)
     fa_t = torch.as_tensor(fa_idx, device=dev) if fa_idx is not None else None
     return data, fa_t, par
+
+
+def make_phantom(shape, nte=32, seed=20260110, snr=80.0, device="cuda"):
+    """A spatially organised volume [nx, ny, nz, nte] for the filters that look at neighbourhoods (TV, NESMA, Gaussian smoothing):
+    an ellipsoidal head of 'grey matter' with a 'white matter' core (higher myelin fraction) and smooth gradients of the
+    compartment T2s, zero outside, Rician noise at the given SNR of the first echo.  Returns (data tensor, mask uint8 tensor)."""
+    nx, ny, nz = shape
+    x, y, z = np.meshgrid(np.linspace(-1, 1, nx), np.linspace(-1, 1, ny), np.linspace(-1, 1, nz), indexing="ij")
+    r2 = (x / 0.9) ** 2 + (y / 0.8) ** 2 + (z / 0.85) ** 2
+    head = r2 < 1.0
+    wm = ((x / 0.55) ** 2 + (y / 0.5) ** 2 + (z / 0.5) ** 2) < 1.0
+    n = nx * ny * nz
+    params = {"MWF": np.where(wm, 0.16 + 0.04 * x, 0.07 + 0.02 * y), "T2m": 22.0 + 4.0 * z, "T2ie": np.where(wm, 70.0, 82.0) + 4.0 * x * y,
+              "SNR": np.full(n, float(snr)), "sm": np.full(n, 2.0), "sie": np.full(n, 9.0)}
+    data, _, _ = make_voxels(n, nte=nte, seed=seed, device=device, params=params)
+    mask = torch.as_tensor(head.reshape(-1), device=data.device)
+    data = data * mask.unsqueeze(1).to(data.dtype)
+    return data.reshape(nx, ny, nz, nte), mask.reshape(nx, ny, nz).to(torch.uint8)

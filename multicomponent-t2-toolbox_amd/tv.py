@@ -1,103 +1,66 @@
 """denoise='TV' of the driver (motor/motor_recon_met2_real_data.py:293-304): per echo volume
     sigma_est = mean(estimate_sigma(vol));  vol <- denoise_tv_chambolle(vol, weight = 2 sigma_est, eps = 2e-4, max_num_iter = 200)
+on the device through `met2_tv_chambolle` (csrc/met2_tv.hip): every echo volume in the same launches, one fused stencil kernel per
+Chambolle iteration, the stopping rule applied on the device.  There is no CPU or torch fallback.
 
-PARITY UNPINNED.  Both functions live in scikit-image (with PyWavelets underneath), neither of which is in this image, so the
-reference's TV branch can be neither run nor turned into fixtures here.  What follows restates the published algorithms:
-  * estimate_sigma: Donoho & Johnstone's robust wavelet estimator -- median(|d|) / Phi^-1(0.75) over the non-zero
-    coefficients d of the finest all-detail sub-band of a separable db2 transform (half-sample symmetric extension, dyadic
-    down-sampling: d[o] = sum_j g[j] x_ext[2 o + 1 - j]);
-  * denoise_tv_chambolle: Chambolle's projection algorithm (J. Math. Imaging Vis. 20, 2004) for min_u |u - f|^2 / 2 + w TV(u)
-    in n dimensions with forward differences, step tau = 1 / (2 n), stopping when the energy changes by less than
-    eps x its first value.
-It is pre-processing outside the hot path: plain torch tensor ops on whatever device the volume lives on (the volume is
-already in HBM when the driver reaches this step); tests check the algorithmic properties, not parity."""
-import math
+PARITY UNPINNED: both functions live in scikit-image (PyWavelets underneath), neither of which is in this image; the kernels restate the
+published algorithms in scikit-image's operation order; tests/test_tv.py checks them against an independent numpy restatement."""
+import ctypes as C
 
+import numpy as np
 import torch
 
-# Daubechies-2 decomposition high-pass filter (PyWavelets' pywt.Wavelet('db2').dec_hi)
-_DB2_DEC_HI = (-0.48296291314469025, 0.836516303737469, -0.22414386804185735, -0.12940952255092145)
-_PHI_INV_075 = 0.6744897501960817          # scipy.stats.norm.ppf(0.75)
+from ._lib import Met2Error, check, lib
 
 
-def _dwt_detail_axis(x, axis):
-    """One level of the db2 high-pass branch along `axis` (symmetric extension, output length (N + 3) // 2)."""
-    n = x.shape[axis]
-    nout = (n + len(_DB2_DEC_HI) - 1) // 2
-    o = torch.arange(nout, device=x.device)
-    out = None
-    for j, g in enumerate(_DB2_DEC_HI):
-        idx = 2 * o + 1 - j
-        idx = torch.where(idx < 0, -idx - 1, idx)
-        idx = torch.where(idx >= n, 2 * n - 1 - idx, idx).clamp(0, n - 1)
-        term = g * x.index_select(axis, idx)
-        out = term if out is None else out + term
-    return out
-
-
-def estimate_sigma(vol):
-    """Robust noise standard deviation of an n-d array (skimage.restoration.estimate_sigma(vol, channel_axis=None))."""
-    d = vol
-    for ax in range(vol.dim()):
-        d = _dwt_detail_axis(d, ax)
-    d = d.reshape(-1)
-    d = d[d != 0].abs()
-    if d.numel() == 0:
-        return 0.0
-    s, _ = torch.sort(d)
-    m = s.numel()
-    med = s[m // 2] if m % 2 else 0.5 * (s[m // 2 - 1] + s[m // 2])
-    return float(med) / _PHI_INV_075
-
-
-def denoise_tv_chambolle(image, weight=0.1, eps=2.0e-4, max_num_iter=200):
-    """Chambolle's projection algorithm on an n-d tensor (skimage.restoration.denoise_tv_chambolle(image, weight, eps, max_num_iter,
-    channel_axis=None)); returns the denoised tensor."""
-    ndim = image.dim()
-    if weight <= 0.0:
-        return image.clone()
-    p = torch.zeros((ndim,) + tuple(image.shape), dtype=image.dtype, device=image.device)
-    g = torch.zeros_like(p)
-    d = torch.zeros_like(image)
-    tau = 1.0 / (2.0 * ndim)
-    out = image
-    e_init = e_prev = 0.0
-    for i in range(max_num_iter):
-        if i > 0:
-            d = -p.sum(dim=0)                                          # minus the divergence of p (backward differences)
-            for ax in range(ndim):
-                n = image.shape[ax]
-                d.narrow(ax, 1, n - 1).add_(p[ax].narrow(ax, 0, n - 1))
-            out = image + d
-        energy = float((d * d).sum())
-        for ax in range(ndim):                                         # forward differences of `out`
-            n = image.shape[ax]
-            g[ax].zero_()
-            g[ax].narrow(ax, 0, n - 1).copy_(out.narrow(ax, 1, n - 1) - out.narrow(ax, 0, n - 1))
-        norm = torch.sqrt((g * g).sum(dim=0))
-        energy += weight * float(norm.sum())
-        norm = norm * (tau / weight) + 1.0
-        p -= tau * g
-        p /= norm.unsqueeze(0)
-        energy /= float(image.numel())
-        if i == 0:
-            e_init = e_prev = energy
-        else:
-            if abs(e_prev - energy) < eps * e_init:
-                break
-            e_prev = energy
-    return out
-
-
-def tv_denoise_volume(data, weight_factor=2.0, eps=2.0e-4, max_num_iter=200):
-    """motor:293-304 on data [nx, ny, nz, nt]: every echo volume through estimate_sigma + denoise_tv_chambolle."""
+def _layout(data):
+    """-> (tensor as it lies in memory, echo_major flag).  A Fortran-ordered [nx,ny,nz,nt] tensor (the order nibabel's arrays have) is
+    read in place as [nt][nz][ny][nx]; anything else is made C-contiguous."""
     if data.dim() != 4:
         raise ValueError("data must be [nx,ny,nz,nt]")
-    out = torch.empty_like(data)
-    for t in range(data.shape[3]):
-        vol = data[..., t].contiguous()
-        sigma = estimate_sigma(vol)
-        if not math.isfinite(sigma):
-            raise ValueError("array must not contain infs or NaNs")
-        out[..., t] = denoise_tv_chambolle(vol, weight_factor * sigma, eps, max_num_iter)
-    return out
+    if not data.is_contiguous() and data.permute(3, 2, 1, 0).is_contiguous():
+        return data, 1
+    return data.contiguous(), 0
+
+
+def tv_chambolle(data, weight=None, weight_factor=2.0, eps=2.0e-4, max_num_iter=200, poll_every=8, device=0, return_info=False):
+    """Every echo volume of data [nx,ny,nz,nt] through denoise_tv_chambolle; `weight` = one weight per echo (array) or None:
+    weight_factor x the echo's estimate_sigma.  numpy in -> numpy out, CUDA tensor in -> tensor out (same memory order).
+    return_info: also (sigma [nt], iterations [nt]) as numpy arrays."""
+    as_numpy = not torch.is_tensor(data)
+    dev = torch.device("cuda", device) if as_numpy else data.device
+    if dev.type != "cuda":
+        raise Met2Error("TV denoising runs on the GPU only; there is no CPU fallback")
+    dd, echo_major = _layout(torch.as_tensor(data, dtype=torch.float64, device=dev))
+    nx, ny, nz, nt = dd.shape
+    out = torch.empty_strided(dd.shape, dd.stride(), dtype=torch.float64, device=dev)
+    if dd.numel() == 0:
+        return (out.cpu().numpy() if as_numpy else out, np.zeros(nt), np.zeros(nt, dtype=np.int32)) if return_info else (out.cpu().numpy() if as_numpy else out)
+    L = lib()
+    nbytes = int(L.met2_tv_work_bytes(nx, ny, nz, nt, echo_major))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    sig = torch.empty(nt, dtype=torch.float64, device=dev)
+    its = torch.empty(nt, dtype=torch.int32, device=dev)
+    wp = None
+    if weight is not None:
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(weight, dtype=np.float64), (nt,)))
+        wp = w.ctypes.data_as(C.POINTER(C.c_double))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        check(L.met2_tv_chambolle(dev.index or 0, nx, ny, nz, nt, dd.data_ptr(), echo_major, wp, float(weight_factor), float(eps),
+                                  int(max_num_iter), int(poll_every), out.data_ptr(), sig.data_ptr(), its.data_ptr(), work.data_ptr(),
+                                  nbytes, stream.cuda_stream))
+        stream.synchronize()                                         # `work` and the host weights stay alive until here
+    res = out.cpu().numpy() if as_numpy else out
+    if return_info:
+        return res, sig.cpu().numpy(), its.cpu().numpy()
+    return res
+
+
+def tv_denoise_volume(data, weight_factor=2.0, eps=2.0e-4, max_num_iter=200, return_info=False):
+    """motor:293-304 on data [nx, ny, nz, nt]: estimate_sigma + denoise_tv_chambolle for every echo volume.  A nan or inf in the data
+    raises like the reference's finite check."""
+    res = tv_chambolle(data, None, weight_factor, eps, max_num_iter, return_info=True)
+    if weight_factor != 0 and not np.isfinite(res[1]).all():
+        raise ValueError("array must not contain infs or NaNs")
+    return res if return_info else res[0]

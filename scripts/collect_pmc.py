@@ -28,9 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = "multicomponent-t2-toolbox_amd"
 
 
-def source_sha():
+def source_sha(files=("met2_hip.hip", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp")):
     h = hashlib.sha256()
-    for f in ("met2_hip.hip", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp"):
+    for f in files:
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--key", required=True, help="entry name in pmc_counters.json: config<N> for a BASELINE config at full size")
     ap.add_argument("--kernel", default="fit_kernel", help="substring of the kernel to report (default: the fit kernel)")
     ap.add_argument("--timeout", type=int, default=900)
+    ap.add_argument("--sha-files", default="", help="comma list of csrc files whose digest the entry carries (default: the fit kernel's sources)")
     ap.add_argument("--sum", action="store_true", help="sum the counters over ALL dispatches of the kernel in the last step (a kernel launched once per pass of voxels)")
     ap.add_argument("bench", nargs=argparse.REMAINDER)
     a = ap.parse_args()
@@ -120,11 +121,11 @@ def main():
     # voxels of the launch: from a plain bench run's JSON line
     p = subprocess.run(["python3", os.path.join(ROOT, "bench.py")] + bench_args, capture_output=True, text=True, timeout=a.timeout)
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    ent = {"tag": a.tag, "src_sha": source_sha(), "kernel": dominant, "voxels": line["config"]["voxels_per_gpu"],
+    ent = {"tag": a.tag, "src_sha": source_sha(tuple(a.sha_files.split(","))) if a.sha_files else source_sha(), "kernel": dominant, "voxels": line["config"]["voxels_per_gpu"],
            "files": "%s_%s_pmc.csv, %s_%s_kernel_stats.csv" % (a.tag, a.key, a.tag, a.key),
            "kernel_avg_ms_rocprof": float(krows[0]["AverageNs"]) / 1e6 if krows else None,
            "kernel_max_ms_rocprof": float(krows[0]["MaxNs"]) / 1e6 if krows and "MaxNs" in krows[0] else None,
-           "kernel_ms_hip_events": line["roofline"].get("fa_kernel_ms") if "fa_kernel" in a.kernel else line["roofline"]["kernel_ms"],
+           "kernel_ms_hip_events": line["roofline"].get("fa_kernel_ms") if "fa_kernel" in a.kernel else line["roofline"].get("kernel_ms", line["roofline"].get("iteration_phase_ms")),
            "bench_args": " ".join(bench_args)}
     if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
         ent["fetch_kb_raw"] = allc["FETCH_SIZE"]; ent["write_kb_raw"] = allc["WRITE_SIZE"]

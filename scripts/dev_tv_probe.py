@@ -1,0 +1,57 @@
+"""GPU probe of the TV denoiser (met2_tv_chambolle): wall time of the whole step on a 128 x 128 x 64 x 32 phantom, iteration counts per
+echo, time per Chambolle iteration and the HBM rate its 56 algorithmic bytes per (voxel, echo) amount to.
+    python3 scripts/dev_tv_probe.py [nx ny nz nt] [--fortran]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "multicomponent-t2-toolbox_amd"
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    shape = tuple(int(a) for a in args[:3]) if len(args) >= 4 else (128, 128, 64)
+    nt = int(args[3]) if len(args) >= 4 else 32
+    synth = importlib.import_module(PKG + ".synth")
+    tv = importlib.import_module(PKG + ".tv")
+    vol, mask = synth.make_phantom(shape, nte=nt, device="cuda:0")
+    if "--fortran" in sys.argv:
+        vol = vol.permute(3, 2, 1, 0).contiguous().permute(3, 2, 1, 0)
+    torch.cuda.synchronize()
+    res = {}
+    for poll in (8, 0):
+        best = None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            out, sig, its = tv.tv_chambolle(vol, poll_every=poll, return_info=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res["wall_ms_poll%d" % poll] = best * 1e3
+    # fixed iteration counts: the per-iteration cost without the tail of finished echoes
+    t = {}
+    for n in (10, 40):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tv.tv_chambolle(vol, weight=np.full(nt, 1e-3 * float(vol.max())), eps=0.0, max_num_iter=n, poll_every=0)
+        ev0.record()
+        tv.tv_chambolle(vol, weight=np.full(nt, 1e-3 * float(vol.max())), eps=0.0, max_num_iter=n, poll_every=0)
+        ev1.record(); torch.cuda.synchronize()
+        t[n] = ev0.elapsed_time(ev1)
+    per_iter = (t[40] - t[10]) / 30.0
+    elems = vol.numel()
+    res.update({"shape": list(shape) + [nt], "iters": its.tolist(), "sigma_first_last": [float(sig[0]), float(sig[-1])],
+                "ms_per_iteration_all_echoes_active": per_iter, "fixed_ms": (t[10] - 10 * per_iter),
+                "algorithmic_GBps": 56.0 * elems / (per_iter * 1e-3) / 1e9,
+                "OY": os.environ.get("MET2_TV_OY", "16"), "XLEN": os.environ.get("MET2_TV_XLEN", "16"),
+                "std_in_out": [float(vol[..., 0].std()), float(out[..., 0].std())]})
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

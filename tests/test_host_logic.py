@@ -27,7 +27,7 @@ def test_library_builds_and_exports_header_symbols():
     for name in declared:
         assert hasattr(L, name), "libmet2_hip.so does not export %s" % name
     assert set(lib.SYMBOLS) == declared
-    assert L.met2_abi_version() == 3
+    assert L.met2_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -305,7 +305,7 @@ def test_ctypes_argtypes_match_the_header_prototypes():
     L = lib.lib()
     header = open(os.path.join(ROOT, "include", "met2_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    protos = re.findall(r"\b(?:int|void|const char \*)\s*(met2_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|void|const char \*)\s*(met2_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
     assert len(protos) >= 28
     checked = 0
     for name, args in protos:
