@@ -114,6 +114,58 @@ __global__ void relayout_kernel(int nte, int nt2, int nfa, const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------
+// GCV's low-rank basis (objectives.hpp, "Round 4"): per flip angle an orthonormal Q (m x 16) of the dominant column space of D by
+// pivoted Gram-Schmidt (the column of largest remaining norm, orthogonalised twice against the vectors found so far), then
+// A = Q^T D from the ORIGINAL dictionary, stored transposed ([bin][16]: a support bin's 16 coefficients are one 128-byte line).
+// res[fa] = largest remaining column norm / largest column norm: what the basis leaves of D.  One wave per flip angle; the
+// remainder R (m x n) lives in LDS, lane <-> column for the sweeps over columns, lane <-> echo for the basis vectors.
+// ------------------------------------------------------------------------------------------
+#define MET2_GCV_LR_TOL 1e-9
+__global__ __launch_bounds__(64) void gcv_basis_kernel(int m, int n, const double *__restrict__ D, double *__restrict__ Aq, double *__restrict__ res)
+{
+    extern __shared__ double basis_lds[];
+    double *R = basis_lds, *Q = basis_lds + (size_t)m * n;             // R[m][n], Q[16][64]
+    const int fa = blockIdx.x, lane = threadIdx.x;
+    const double *Df = D + (size_t)fa * m * n;
+    for (int i = lane; i < m * n; i += 64) R[i] = Df[i];
+    for (int i = lane; i < MET2_GCV_LR_RANK * 64; i += 64) Q[i] = 0.0;
+    __syncthreads();
+    auto colnorm2 = [&](int j) { double sum = 0.0; for (int e = 0; e < m; ++e) { const double v = R[e * n + j]; sum = fma(v, v, sum); } return sum; };
+    double nrm0 = 0.0;
+    for (int s = 0; s < MET2_GCV_LR_RANK; ++s) {
+        const double c0 = lane < n ? colnorm2(lane) : -1.0, c1 = lane + 64 < n ? colnorm2(lane + 64) : -1.0;
+        const double mx = wave_max(fmax(c0, c1));
+        if (s == 0) nrm0 = mx;
+        if (!(mx > nrm0 * 1e-30)) break;                                // nothing left above rounding: the dictionary has rank s
+        const u64 b0 = ballot(c0 == mx), b1 = ballot(c1 == mx);
+        const int piv = b0 ? first_lane(b0) : 64 + first_lane(b1);
+        double q = lane < m ? R[lane * n + piv] : 0.0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int t = 0; t < s; ++t) { const double qt = Q[t * 64 + lane]; const double d = wave_sum(q * qt); q = fma(-d, qt, q); }
+        q = q / sqrt(wave_sum(q * q));
+        Q[s * 64 + lane] = q;
+        __syncthreads();
+        for (int j = lane; j < n; j += 64) {                            // R -= q (q^T R)
+            double a = 0.0;
+            for (int e = 0; e < m; ++e) a = fma(Q[s * 64 + e], R[e * n + j], a);
+            for (int e = 0; e < m; ++e) R[e * n + j] = fma(-a, Q[s * 64 + e], R[e * n + j]);
+        }
+        __syncthreads();
+    }
+    {
+        const double c0 = lane < n ? colnorm2(lane) : -1.0, c1 = lane + 64 < n ? colnorm2(lane + 64) : -1.0;
+        const double mx = wave_max(fmax(c0, c1));
+        if (lane == 0) res[fa] = nrm0 > 0.0 ? sqrt(fmax(mx, 0.0) / nrm0) : 0.0;
+    }
+    for (int j = lane; j < n; j += 64)
+        for (int s = 0; s < MET2_GCV_LR_RANK; ++s) {
+            double a = 0.0;
+            for (int e = 0; e < m; ++e) a = fma(Q[s * 64 + e], Df[e * n + j], a);
+            Aq[((size_t)fa * n + j) * MET2_GCV_LR_RANK + s] = a;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // voxel classification and counting sort by FA index
 // ------------------------------------------------------------------------------------------
 struct SortBufs {
@@ -223,6 +275,9 @@ __global__ __launch_bounds__(256) void requeue_overflow_kernel(int64_t nvox, con
 #ifndef MET2_BAYES_TABLE
 #define MET2_BAYES_TABLE 10               // shared Brent abscissae with plan-level factors (0 disables the tables)
 #endif
+// Internal kernel variant of MET2_GCV (not part of the ABI): the trace from the 17 x 17 form in the plan's low-rank basis (objectives.hpp,
+// gcv_basis_kernel); chosen by fit_impl when every flip angle's dictionary is of numerical rank <= 16.
+#define MET2_GCV_LR 6
 struct FitArgs {
     int n, m, nfa, kmax, waves, chunk;
     int wave_doubles;   // LDS doubles owned by each wave (>= kmax(kmax+1)/2; n*n for GCV)
@@ -233,6 +288,7 @@ struct FitArgs {
     const double *Dfa;    // [nfa][m][n]
     const double *Bfa;    // [nfa][n][n]
     const double *Dtfa;   // [nfa][n][m]
+    const double *Aq;     // [nfa][n][16]: Q^T D of the flip angle, transposed (MET2_GCV_LR), or NULL
     const double *kband;  // [5][64]
     const double *lband;  // [5][64]
     const double *Kd;     // [n][n] dense L^T L
@@ -452,7 +508,7 @@ __device__ __forceinline__ void load_band(Band<NB> &bd, const double *kband, con
 __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 {
     const int base = method >= 10 ? method - 10 : method;
-    if (base == MET2_GCV) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
+    if (base == MET2_GCV || base == MET2_GCV_LR) return (nb == 2) ? 8 : MET2_GCV_WAVES;      // two bins per lane: the LDS holds 7 waves anyway -> 256 VGPRs, no spills;
                                                                       // one bin per lane: the latency-bound recurrences want waves, the spills of a 128-VGPR build go to HBM
     if (base == MET2_BAYESREG) return (nb == 2) ? 8 : MET2_BAYES_WAVES;  // two bins per lane: 241 VGPRs; the factor is built a block row at a time (chol_lean)
     // two bins per lane: the factor's LDS footprint (kmax = 72 at nT2 = 120) holds 7 waves per CU anyway, so those kernels are
@@ -624,7 +680,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
         const int first = A.sb.bucket_start[fa] + (c - A.sb.chunk_start[fa]) * A.chunk;
         const int cnt = min(A.chunk, A.sb.bucket_start[fa + 1] - first);
         S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
-        S.DtG = S.Dt;
+        S.DtG = ((METHOD >= 10 ? METHOD - 10 : METHOD) == MET2_GCV_LR) ? A.Aq + (size_t)fa * n * MET2_GCV_LR_RANK : S.Dt;
         const int seed_k = (MET2_SEED && A.seed) ? ((const SeedRec *)A.seed)[fa].k : 0;
         const bool have_seed = seed_k > 0 && seed_k <= kmax;
         for (int slot = 0; slot < cnt; ++slot) {
@@ -784,7 +840,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 if (bc.failed) stat |= MET2_ST_CHOLFAIL;
                 if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
                 regv = lamv = lam;
-            } else if (METHOD == MET2_GCV) {
+            } else if (METHOD == MET2_GCV || METHOD == MET2_GCV_LR) {
                 // algorithms.py:276-283
                 int flag, overflow = 0;
                 GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
@@ -792,7 +848,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                 double lam = fminbound_dev([&](double x) {
                     if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
                     nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
-                    return gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
+                    return gcv_objective<NB, METHOD == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
                 }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
                 if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
                 if (overflow) stat |= MET2_ST_KOVERFLOW;
@@ -820,7 +876,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                     nnls_solve<NB>(S, bd, st, x, true, lane);
                     double val;
                     if (BASE == MET2_X2) val = fabs(sse_of<NB>(S, st, b, lane) - A.x2_factor * SSE) / SSE;
-                    else if (BASE == MET2_GCV) val = gcv_objective<NB>(S, bd, st, x, b, lane, overflow, gc);
+                    else if (BASE == MET2_GCV || BASE == MET2_GCV_LR) val = gcv_objective<NB, BASE == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
                     else val = bayes_objective<NB>(S, bd, st, bc, x, b, lane);
                     if (lane == i) keep = val;
                 }
@@ -1466,6 +1522,8 @@ struct met2_plan {
                                                           // flip angle 0): only then is the seeded start the cold start's solution
     double *dH = nullptr; int64_t cap_h = 0;              // FA walk: h of every flip angle for one pass of voxels (fa_project_kernel), grown on demand
     double *dBtab = nullptr; int btab_stride = 0;         // BayesReg factor tables [nfa][MET2_BAYES_TABLE][btab_stride] (built with the seeds)
+    double *dAq = nullptr, *dAqRes = nullptr;             // GCV: [nfa][n_t2][16] = (Q^T D)^T in the flip angle's low-rank basis, [nfa] what the basis leaves of D
+    bool gcv_lr = false;                                  // every flip angle's dictionary is of numerical rank <= 16: the GCV trace takes the 17 x 17 form
     double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
     int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
@@ -1549,6 +1607,7 @@ static int fit_geometry(const met2_plan *p, int method, LaunchGeom &g, int kmax_
     g.kmax = (kmax_cap > 0 && kmax_cap < n) ? kmax_cap : n;
     g.wave_doubles = col_base(g.kmax);                                 // the factor, packed by columns without padding (nnls_wave.hpp)
     if (base == MET2_GCV && gcv_lds_doubles(m, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(m, n);      // M ((m+1)^2) + vectors + support list
+    if (base == MET2_GCV_LR && gcv_lds_doubles(MET2_GCV_LR_RANK, n) > g.wave_doubles) g.wave_doubles = gcv_lds_doubles(MET2_GCV_LR_RANK, n);
     if (method == MET2_BAYESREG && g.nb == 2 && chol_panel_doubles(n) > g.wave_doubles) g.wave_doubles = chol_panel_doubles(n);   // chol_lean's 16-row panel
     g.wave_doubles = (g.wave_doubles + 1) & ~1;                        // every wave's region starts 16-byte aligned
     // D, D^T, B and K are read through L1/L2: with warm starts a lambda evaluation reads only ~k rows of B, and the LDS is worth
@@ -1613,7 +1672,7 @@ static int fast_kmax(const met2_plan *p, int method)
 // 118): for it a middle pass means solving them three times (measured: 6.7 -> 10 ms), so it gets none.  0: no middle pass.
 static int mid_kmax(const met2_plan *p, int method, int kfast)
 {
-    if (!kfast || p->n_t2 <= 64 || method != MET2_GCV) return 0;
+    if (!kfast || p->n_t2 <= 64 || (method != MET2_GCV && method != MET2_GCV_LR)) return 0;
     { const int kk = tuning_env("MET2_KMID", 0, p->n_t2 - 1, -1); if (kk >= 0) return kk > kfast ? kk : 0; }
     int k3 = kfast;
     while (k3 + 1 < p->n_t2 && 3 * sizeof(double) * (size_t)col_base(k3 + 1) <= 160 * 1024 - 64) ++k3;
@@ -1658,6 +1717,8 @@ static int launch_method(int method, const FitArgs &A, const LaunchGeom &g, hipS
 #if MET2_HAS(4)
     case 10 + MET2_GCV: return launch_fit<10 + MET2_GCV>(A, g, s);
     case MET2_GCV: return launch_fit<MET2_GCV>(A, g, s);      // its clean-up pass runs the same kernel symbol
+    case 10 + MET2_GCV_LR: return launch_fit<10 + MET2_GCV_LR>(A, g, s);
+    case MET2_GCV_LR: return launch_fit<MET2_GCV_LR>(A, g, s);
 #endif
 #if MET2_HAS(5)
     case 10 + MET2_BAYESREG: return launch_fit<10 + MET2_BAYESREG>(A, g, s);
@@ -1956,6 +2017,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dD, sizeof(double) * (size_t)n_fa * n_te * n_t2));
     HIPCHK(hipMalloc(&p->dB, sizeof(double) * (size_t)n_fa * n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dDt, sizeof(double) * (size_t)n_fa * n_te * n_t2));
+    HIPCHK(hipMalloc(&p->dAq, sizeof(double) * (size_t)n_fa * n_t2 * MET2_GCV_LR_RANK));
+    HIPCHK(hipMalloc(&p->dAqRes, sizeof(double) * (size_t)n_fa));
     HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dKd, sizeof(double) * (size_t)n_t2 * n_t2));
@@ -1994,7 +2057,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
+    void *bufs[] = {p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -2004,10 +2067,21 @@ int met2_plan_destroy(met2_plan *p)
     return MET2_OK;
 }
 
+// Everything that is derived from the dictionary alone: Gram matrices, the transposed copy, GCV's low-rank basis.  Blocks (its callers do).
 static int build_gram(met2_plan *p, hipStream_t s)
 {
     hipLaunchKernelGGL(gram_kernel, dim3(p->n_fa), dim3(256), 0, s, p->n_te, p->n_t2, p->dD, p->dB, p->dDt);
     HIPCHK(hipGetLastError());
+    const int lds = (int)sizeof(double) * (p->n_te * p->n_t2 + MET2_GCV_LR_RANK * 64);
+    HIPCHK(hipFuncSetAttribute((const void *)gcv_basis_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(gcv_basis_kernel, dim3(p->n_fa), dim3(64), lds, s, p->n_te, p->n_t2, p->dD, p->dAq, p->dAqRes);
+    HIPCHK(hipGetLastError());
+    std::vector<double> res(p->n_fa);
+    HIPCHK(hipMemcpyAsync(res.data(), p->dAqRes, sizeof(double) * p->n_fa, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    bool ok = true;
+    for (double r : res) ok = ok && (r <= MET2_GCV_LR_TOL);          // (nan: not low rank)
+    p->gcv_lr = ok;
     p->have_dict = true; p->seeds_valid = false;
     return MET2_OK;
 }
@@ -2225,11 +2299,14 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     if (rc) return rc;
     // capacity scheme: pass 1 with a passive-set capacity kfast < n (more waves per CU), pass 2 with the full
     // capacity for the voxels that hit it
-    const int kfast = objgrid ? 0 : fast_kmax(p, method);
+    // the kernel variant: GCV takes its trace from the 17 x 17 low-rank form when the plan's dictionary allows it (MET2_GCV_FULL=1: test
+    // switch, the (m + 1) x (m + 1) form always)
+    const int kmeth = (method == MET2_GCV && p->gcv_lr && !getenv("MET2_GCV_FULL")) ? MET2_GCV_LR : method;
+    const int kfast = objgrid ? 0 : fast_kmax(p, kmeth);
     LaunchGeom g, g2;
-    rc = fit_geometry(p, objgrid ? method + 10 : method, g, kfast, 0, nvox);
+    rc = fit_geometry(p, objgrid ? kmeth + 10 : kmeth, g, kfast, 0, nvox);
     if (rc) return rc;
-    if (kfast) { rc = fit_geometry(p, method, g2, 0, 0, nvox); if (rc) return rc; }
+    if (kfast) { rc = fit_geometry(p, kmeth, g2, 0, 0, nvox); if (rc) return rc; }
     if (kfast && !status) {        // the second pass is driven by the status words
         if (p->cap_status < nvox) {
             if (p->dStatus) HIPCHK(hipFree(p->dStatus));
@@ -2279,7 +2356,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
     A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
     A.log_detL = p->log_detL;
-    A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
+    A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Aq = p->dAq; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
     A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     A.seed = nullptr;
@@ -2308,7 +2385,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     }
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }
-    rc = launch_method(objgrid ? method + 10 : method, A, g, s);
+    rc = launch_method(objgrid ? kmeth + 10 : kmeth, A, g, s);
     if (rc) return rc;
     HIPCHK(hipEventRecord(p->ev1, s));
     if (kfast) {
@@ -2322,13 +2399,13 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
         hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
         HIPCHK(hipGetLastError());
         FitArgs A2 = A;
-        const int kmid = mid_kmax(p, method, kfast);
+        const int kmid = mid_kmax(p, kmeth, kfast);
         if (kmid) {                                         // middle rung: same kernel at capacity kmid; what still overflows is queued once more
             LaunchGeom gm;
-            rc = fit_geometry(p, method, gm, kmid, 0, -1);
+            rc = fit_geometry(p, kmeth, gm, kmid, 0, -1);
             if (rc) return rc;
             A2.kmax = gm.kmax; A2.waves = gm.waves; A2.wave_doubles = gm.wave_doubles;
-            rc = launch_method(method, A2, gm, s, true);
+            rc = launch_method(kmeth, A2, gm, s, true);
             if (rc) return rc;
             HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 1), s));
             HIPCHK(hipMemsetAsync(sb.xq, 0, sizeof(int) * 8, s));
@@ -2338,7 +2415,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
             HIPCHK(hipGetLastError());
         }
         A2.kmax = g2.kmax; A2.waves = g2.waves; A2.wave_doubles = g2.wave_doubles;
-        rc = launch_method(method, A2, g2, s, true);
+        rc = launch_method(kmeth, A2, g2, s, true);
         if (rc) return rc;
         HIPCHK(hipEventRecord(p->ev2, s));
         p->timed2 = true;
@@ -2555,6 +2632,7 @@ int met2_plan_launch_info(met2_plan *p, int32_t method, int32_t *grid, int32_t *
 {
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
     LaunchGeom g;
+    if (method == MET2_GCV && p->gcv_lr && !getenv("MET2_GCV_FULL")) method = MET2_GCV_LR;      // the variant fit_impl launches
     const int kf = fast_kmax(p, method);
     int rc = fit_geometry(p, method, g, kf);
     if (rc) return rc;

@@ -521,6 +521,20 @@ __device__ __forceinline__ double bayes_objective(const WaveShared &S, const Ban
 // row 16-byte aligned: the sweeps read and write with ds_read/write_b128) and = 2 mod 4: then the 16 lanes of a b128 lane group, each
 // on its own row, fall on 16 different four-dword bank groups (2 np mod 64 is an odd multiple of 4) -- conflict-free.
 // The support list (read by the Gram contraction only) shares the room of the vectors (written after it).
+//
+// Round 4: the same trace from a 17 x 17 matrix (LR = true).  The dictionary of a flip angle is numerically of low rank -- its singular
+// values fall by a factor 4-8 per index (1e-10 at index 16 for 48 x 120, 1e-12 for 32 x 60) -- so with an orthonormal basis Q (m x 16) of
+// its dominant column space (gcv_basis_kernel: pivoted Gram-Schmidt, once per plan and flip angle) and A = Q^T D (16 x n) one has
+// Dr = Q A_S up to 1e-10 sigma_max, C = Dr Dr^T = Q (A_S A_S^T) Q^T and b = Q (A_S 1): M is blockdiag(1, Q) M' blockdiag(1, Q)^T with
+//     M' = [[c k, sqrt(c) beta^T], [sqrt(c) beta, W]],   W = A_S A_S^T (16 x 16: ONE mfma tile),   beta = A_S 1,
+// and the eigenvalues of M above the cut and the first components of their eigenvectors are those of M' (the part of Dr outside Q
+// is orthogonal to it, so it moves the eigenvalues only in second order: <= 1e-20 sigma_max^2, four decades under the rounding noise
+// of the reference's own G).  Numpy on 360 (voxel, lambda) pairs at 48 x 120: |trace(M') - trace(M)| median 8e-10, the numerical
+// rank differs in 1 of 360 (an eigenvalue on the cut, where M and the reference's lstsq differ from each other as well), and the
+// distance to the reference's formula is the same for both (median 5.8e-5, p90 6.9e-4).  Everything downstream -- tridiagonalisation,
+// multisection, weights -- is the code below with m = 16: 15 Householder steps on 16 rows instead of 47 on 48, Sturm chains of 17 rows
+// instead of 49, 2.7 KB of LDS instead of 20.4.  A plan whose dictionary is NOT of numerical rank <= 16 keeps the full form.
+#define MET2_GCV_LR_RANK 16
 __host__ __device__ inline int gcv_cols(int m) { return (m + 3) & ~3; }
 __host__ __device__ inline int gcv_row_stride(int m) { int np = gcv_cols(m); while ((np & 3) != 2) ++np; return np; }
 __host__ __device__ inline int gcv_vec_len(int m) { return gcv_cols(m); }
@@ -608,7 +622,7 @@ struct GcvCache {                  // a few entries: Brent's last steps often al
     int next;          // entry the next miss overwrites: the one after the entry used last
 };
 
-template <int NB>
+template <int NB, bool LR = false>
 __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, double c, const int *list, int lane, GcvCache<NB> &tc, bool reuse, int slot,
                                                    unsigned long long *cyc = nullptr)
 {
@@ -619,8 +633,8 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 #else
 #define MET2_GCV_LAP(slot)
 #endif
-    const int m = S.m, n = m + 1, np = gcv_row_stride(m);      // n: order of T
-    double *M = S.R;                         // C = M[1.., 1..]: [m][np], lane a <-> row a of C = row a + 1 of M
+    const int m = LR ? MET2_GCV_LR_RANK : S.m, n = m + 1, np = gcv_row_stride(m);      // n: order of T
+    double *M = S.R;                         // C (LR: W) = M[1.., 1..]: [m][np], lane a <-> row a of C = row a + 1 of M
     double *vb = M + m * np;                 // [gcv_cols] Householder vector, zero padded (the support list sits here during step 1)
     double *wb = vb + gcv_vec_len(m);
     double *vb2 = wb + gcv_vec_len(m);       // the Householder vectors alternate between vb and vb2
@@ -630,6 +644,30 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
     // ---- 1. M = A A^T on the matrix cores
     {
         const int li = lane & 15, lk = lane >> 4;
+        double bvec = 0.0;
+        if (LR) {
+            // W = A_S A_S^T: one 16 x 16 tile; S.DtG is the flip angle's A^T, [bin][16] -- four support bins = 64 contiguous doubles per k-step.
+            // beta = A_S 1 falls out of the same operands.
+            met2_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int r0 = 0; r0 < k; r0 += 16) {
+                double a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rr = r0 + 4 * q + lk;
+                    const double va = S.DtG[(size_t)list[min(rr, k - 1)] * MET2_GCV_LR_RANK + li];
+                    a[q] = (rr < k) ? va : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (r0 + 4 * q < k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], a[q], acc, 0, 0, 0);
+                    bvec += a[q];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) M[(lk + 4 * v) * np + li] = acc[v];
+            bvec += gather(bvec, lane ^ 16);
+            bvec += gather(bvec, lane ^ 32);                             // lanes li, li + 16, ...: beta[li]
+        } else {
         const int nt = (n + 15) >> 4;
         for (int ti = 0; ti < nt; ++ti)
             for (int tj = ti; tj < nt; ++tj) {
@@ -659,7 +697,6 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
             }
         // column 0 of M below its diagonal: b = Dr 1 (row sums of D over the support), lane e <-> echo e; parked in wb until the
         // first reflector has been built from it (wb takes that step's w afterwards)
-        double bvec = 0.0;
         {
             const int le = min(lane, m - 1);
             for (int r0 = 0; r0 < k; r0 += 4) {
@@ -669,6 +706,7 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bvec += (r0 + q < k) ? t[q] : 0.0;
             }
+        }
         }
         __builtin_amdgcn_wave_barrier();                                 // (the list is dead from here: the vectors' room takes b and the padding)
         if (lane < m) wb[lane] = sc * bvec;
@@ -902,11 +940,11 @@ __device__ __forceinline__ double gcv_trace_direct(const WaveShared &S, int k, d
 
 // algorithms.py:285-296 given the NNLS solution st.x at lambda = x:
 //   log( (r^2/m) / ((m - trace(Dr G^+ Dr^T))/m)^2 )
-template <int NB>
+template <int NB, bool LR = false>
 __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<NB> &bd, const NnlsState<NB> &st, double x, double b,
                                                 int lane, int &overflow, GcvCache<NB> &tc)
 {
-    const int n = S.n, m = S.m;
+    const int n = S.n, m = S.m, mt = LR ? MET2_GCV_LR_RANK : S.m;      // mt: order of the matrix the trace is taken from
 #ifdef MET2_CYCSTATS
     NnlsState<NB> &stw = const_cast<NnlsState<NB> &>(st);
 #endif
@@ -925,7 +963,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
         l2 += inS[bb] ? ld * ld : 0.0;
     }
     if (k == 0) return NAN;
-    if (gcv_lds_doubles(m, k) > S.rcap) { overflow = 1; return INFINITY; }
+    if (gcv_lds_doubles(mt, k) > S.rcap) { overflow = 1; return INFINITY; }
     const double c = x * wave_sum(l2);
     int slot = -1;
 #pragma unroll
@@ -939,7 +977,7 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     if (!reuse) slot = tc.next;
     tc.next = (slot + 1 == MET2_GCV_CACHE) ? 0 : slot + 1;             // two entries: a miss overwrites the one not used last
     // support list (ascending bins) behind C in the wave's LDS region (where the Householder vectors go once the Gram contraction has read it)
-    int *list = (int *)(S.R + m * gcv_row_stride(m));
+    int *list = (int *)(S.R + mt * gcv_row_stride(mt));
     if (!reuse) {
         int base = 0;
 #pragma unroll
@@ -957,9 +995,9 @@ __device__ __forceinline__ double gcv_objective(const WaveShared &S, const Band<
     const unsigned long long cs0 = __builtin_readcyclecounter();
 #endif
 #ifdef MET2_CYCSTATS
-    const double tr = gcv_trace_direct<NB>(S, k, c, list, lane, tc, reuse, slot, stw.cyc);
+    const double tr = gcv_trace_direct<NB, LR>(S, k, c, list, lane, tc, reuse, slot, stw.cyc);
 #else
-    const double tr = gcv_trace_direct<NB>(S, k, c, list, lane, tc, reuse, slot);
+    const double tr = gcv_trace_direct<NB, LR>(S, k, c, list, lane, tc, reuse, slot);
 #endif
 #ifdef MET2_CYCSTATS
     stw.cyc[5] += __builtin_readcyclecounter() - cs0; stw.cyc[6] += 1; stw.cyc[4] += k;
