@@ -271,6 +271,12 @@ int met2_plan_last_second_pass_ms(met2_plan *plan, double *ms);
  * dynamic LDS bytes per workgroup. */
 int met2_plan_launch_info(met2_plan *plan, int32_t method, int32_t *grid, int32_t *block, int32_t *lds_bytes);
 
+/* Which form of the GCV trace (algorithms.py:285-296) met2_fit takes on this plan (for reports and tests): low_rank = 1 when every
+ * flip angle's dictionary is of numerical rank <= 16 -- an orthonormal basis of 16 vectors leaves less than 1e-9 of its largest
+ * column, `residual` = the largest such remainder over the flip angles -- and the trace is taken from the 17 x 17 matrix in that
+ * basis (true for EPG dictionaries: ~1e-10 at 48 x 120, ~1e-12 at 32 x 60); 0: from the (n_te + 1) x (n_te + 1) matrix. */
+int met2_plan_gcv_form(met2_plan *plan, int32_t *low_rank, double *residual);
+
 #ifdef __cplusplus
 }
 #endif

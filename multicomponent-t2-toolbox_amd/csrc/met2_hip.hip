@@ -1523,6 +1523,7 @@ struct met2_plan {
     double *dH = nullptr; int64_t cap_h = 0;              // FA walk: h of every flip angle for one pass of voxels (fa_project_kernel), grown on demand
     double *dBtab = nullptr; int btab_stride = 0;         // BayesReg factor tables [nfa][MET2_BAYES_TABLE][btab_stride] (built with the seeds)
     double *dAq = nullptr, *dAqRes = nullptr;             // GCV: [nfa][n_t2][16] = (Q^T D)^T in the flip angle's low-rank basis, [nfa] what the basis leaves of D
+    double gcv_res = 0.0;                                 // the largest of dAqRes
     bool gcv_lr = false;                                  // every flip angle's dictionary is of numerical rank <= 16: the GCV trace takes the 17 x 17 form
     double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
@@ -2080,7 +2081,8 @@ static int build_gram(met2_plan *p, hipStream_t s)
     HIPCHK(hipMemcpyAsync(res.data(), p->dAqRes, sizeof(double) * p->n_fa, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     bool ok = true;
-    for (double r : res) ok = ok && (r <= MET2_GCV_LR_TOL);          // (nan: not low rank)
+    p->gcv_res = 0.0;
+    for (double r : res) { ok = ok && (r <= MET2_GCV_LR_TOL); p->gcv_res = (r > p->gcv_res || r != r) ? r : p->gcv_res; }      // (nan: not low rank)
     p->gcv_lr = ok;
     p->have_dict = true; p->seeds_valid = false;
     return MET2_OK;
@@ -2625,6 +2627,15 @@ int met2_plan_last_second_pass_ms(met2_plan *p, double *ms)
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, p->ev1, p->ev2));
     *ms = (double)f;
+    return MET2_OK;
+}
+
+int met2_plan_gcv_form(met2_plan *p, int32_t *low_rank, double *residual)
+{
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    if (!p->have_dict) return fail(MET2_E_STATE, "no dictionary in the plan");
+    if (low_rank) *low_rank = (p->gcv_lr && !getenv("MET2_GCV_FULL")) ? 1 : 0;
+    if (residual) *residual = p->gcv_res;
     return MET2_OK;
 }
 

@@ -311,6 +311,12 @@ class Met2Plan:
         check(lib().met2_plan_last_second_pass_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def gcv_form(self):
+        """(low_rank, residual): whether GCV's trace is taken from the 17 x 17 form in the dictionary's low-rank basis on this plan."""
+        lr, res = C.c_int32(0), C.c_double(0.0)
+        check(lib().met2_plan_gcv_form(self._h, C.byref(lr), C.byref(res)))
+        return bool(lr.value), res.value
+
     def launch_info(self, method="X2"):
         g, b, l = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         check(lib().met2_plan_launch_info(self._h, METHODS[method], C.byref(g), C.byref(b), C.byref(l)))
