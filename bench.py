@@ -330,12 +330,17 @@ def main():
                     help="single: constant FA 150 deg; brute-force: per-voxel FA drawn from the 91-grid and estimated on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true", help="N > 1: run rank 0's CPU baseline all the same (default there: skipped, the other ranks would idle)")
+    ap.add_argument("--end-to-end", action="store_true", help="N > 1: run rank 0's host-to-host leg all the same")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--parity-sample", type=int, default=1 << 17, help="upper bound on the voxels the oracle is run on for the parity block")
     ap.add_argument("--dump-fail", type=str, default="", help="npz path: inputs/outputs of sample voxels whose fsol is >1e-5 off the oracle")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1:       # the CPU baseline and the host-to-host leg are rank 0's alone (15-25 s with N - 1 GPUs idle): single-GPU runs report them
+        args.no_cpu_baseline = not args.cpu_baseline
+        args.no_end_to_end = not args.end_to_end
 
     # ---- N > 1 without a torchrun environment: this process only starts the ranks (no GPU call before this point)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -409,9 +414,44 @@ def main():
     counts = [mdist.shard_count(nvox_total, r, world) for r in range(world)] if strong else [nvox] * world
     maxlen = max(counts)
     gather_all = args.gather == "all"
-    W = (nt2 + nte + 1 + 6) if gather_all else 7
-    gather_bufs = None
-    send = torch.zeros((maxlen, W), dtype=torch.float64, device="cpu" if gloo else dev) if world > 1 else None
+    WIDTH = {"maps": 7, "all": nt2 + nte + 1 + 6}
+    W = WIDTH[args.gather]
+    gdev = "cpu" if gloo else dev
+    sends = {}; gbufs = {}
+
+    def do_gather(res, kind):
+        """The path's single collective: ONE packed buffer per rank to the root (direct peer -> root over xGMI; gloo moves host copies)."""
+        if kind not in sends:
+            sends[kind] = torch.zeros((maxlen, WIDTH[kind]), dtype=torch.float64, device=gdev)
+            gbufs[kind] = [torch.empty_like(sends[kind]) for _ in range(world)] if rank == 0 else None
+        send = sends[kind]
+        if kind == "all":
+            send[:nvox, :nt2].copy_(res["fsol"])
+            send[:nvox, nt2:nt2 + nte].copy_(res["sig"])
+            send[:nvox, nt2 + nte].copy_(res["reg"])
+            send[:nvox, nt2 + nte + 1:].copy_(res["maps"].t())
+        else:
+            send[:nvox, :6].copy_(res["maps"].t())
+            send[:nvox, 6].copy_(res["reg"])
+        dist.gather(send, gbufs[kind], dst=0)
+
+    gather_ms = []
+
+    class GatherTimer:
+        """ms of one packed gather: HIP events on the launch stream under RCCL, host clock under gloo (the collective runs on the host there)."""
+        def __enter__(self):
+            if gloo:
+                torch.cuda.synchronize(); self.t0 = time.perf_counter()
+            else:
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); self.e0.record()
+            return self
+        def __exit__(self, *a):
+            if gloo:
+                self.t1 = time.perf_counter()
+            else:
+                self.e1.record()
+        def ms(self):
+            return 1e3 * (self.t1 - self.t0) if gloo else self.e0.elapsed_time(self.e1)
 
     def step():
         fa_idx = None
@@ -419,19 +459,10 @@ def main():
             fa_idx, _, _ = plan.fa_bruteforce(data)
             fa_ms.append(plan.last_kernel_ms())
         res = plan.fit(method, data, fa_index=fa_idx, out=out, want_lambda=True)
-        if world > 1:   # the path's single collective: one packed buffer per rank to the root over xGMI
-            nonlocal gather_bufs
-            if gather_all:
-                send[:nvox, :nt2].copy_(res["fsol"])
-                send[:nvox, nt2:nt2 + nte].copy_(res["sig"])
-                send[:nvox, nt2 + nte].copy_(res["reg"])
-                send[:nvox, nt2 + nte + 1:].copy_(res["maps"].t())
-            else:
-                send[:nvox, :6].copy_(res["maps"].t())
-                send[:nvox, 6].copy_(res["reg"])
-            if rank == 0 and gather_bufs is None:
-                gather_bufs = [torch.empty_like(send) for _ in range(world)]
-            dist.gather(send, gather_bufs if rank == 0 else None, dst=0)
+        if world > 1:
+            with GatherTimer() as gt:
+                do_gather(res, args.gather)
+            gather_ms.append(gt)
         return res
 
     def sync():
@@ -451,10 +482,30 @@ def main():
         pass2_ms.append(plan.last_second_pass_ms())
     sync()
     dt = time.perf_counter() - t0
+    multi = None
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # per-rank numbers of the timed steps: the solver kernel and the collective (packing + gather, HIP events on the launch stream)
+        g_timed = float(np.mean([g_.ms() for g_ in gather_ms[-args.steps:]]))
+        mine = torch.tensor([float(np.mean(kernel_ms)), g_timed], dtype=torch.float64, device=gdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        # both payloads once more, untimed for `value`: the maps' 56 B/voxel and SURVEY section 8e's full 8 (nT2 + nTE + 7) B/voxel in the same run
+        each = {}
+        for kind in ("maps", "all"):
+            do_gather(out, kind)                       # (allocates the buffers of the kind the timed steps did not use)
+            sync()
+            with GatherTimer() as gt:
+                do_gather(out, kind)
+            sync()
+            t1 = torch.tensor([gt.ms()], dtype=torch.float64, device=gdev)
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            each[kind] = {"ms_max_over_ranks": float(t1.item()), "bytes_per_voxel": 8 * WIDTH[kind], "bytes_per_rank": 8 * WIDTH[kind] * maxlen}
+        multi = {"kernel_ms_per_rank": [float(v) for v in allr[:, 0]], "kernel_ms_min": float(allr[:, 0].min()), "kernel_ms_max": float(allr[:, 0].max()),
+                 "gather_ms_in_timed_steps_per_rank": [float(v) for v in allr[:, 1]], "gather_ms": each}
 
     if rank == 0:
         fitted = int((out["status"] > 0).sum().item())
@@ -506,6 +557,8 @@ def main():
                          "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "bytes_per_voxel": bpv, "counters": pmc_note,
                          "note": "fp64 VALU-issue-bound active-set iteration, not HBM-bound (DESIGN.md section 6)"},
         }
+        if multi:
+            line["multi_gpu"] = multi
         if valu:
             line["roofline"]["valu"] = valu
         if brute:

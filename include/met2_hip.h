@@ -16,8 +16,15 @@
  *     asynchronous with respect to the host unless stated otherwise;
  *   - every function returns 0 on success, a negative MET2_E_* code otherwise;
  *     met2_last_error() gives the message of the calling thread's last failure;
- *   - a plan may be used from one host thread at a time; different plans (e.g. one per
- *     device) may be used concurrently.
+ *   - a plan may be used from one host thread at a time and serves one stream at a time (its sort scratch, error word and
+ *     timing events are per plan: a fit or met2_plan_finish on another stream while enqueued fits are pending returns
+ *     MET2_E_STATE); different plans may be used concurrently, on one device or on several;
+ *   - multi-GPU: the library keeps no global state besides the calling thread's error message,
+ *     so the multi-GPU driver is "one plan per device (met2_options.device), each driven by its own host thread or process,
+ *     all at once": dist.py does that with one process per GPU under torch.distributed,
+ *     tests/test_round4.py::test_two_host_threads_two_plans_run_concurrently with two threads.  The path's single collective --
+ *     the gather of the outputs to the root -- belongs to the host's communicator (RCCL through torch.distributed), so there is
+ *     deliberately no multi-device entry behind this C ABI.
  */
 #ifndef MET2_HIP_H
 #define MET2_HIP_H
@@ -60,7 +67,7 @@ enum met2_error {
     MET2_E_UNSUPPORTED = -2,   /* shape/penalty outside the built kernels */
     MET2_E_HIP = -3,           /* a HIP runtime call failed               */
     MET2_E_NODEVICE = -4,      /* no gfx950 device visible                */
-    MET2_E_STATE = -5          /* plan not fully configured for this call */
+    MET2_E_STATE = -5          /* plan not fully configured for this call, or fits pending on another stream */
 };
 
 typedef struct met2_plan met2_plan;
@@ -156,7 +163,8 @@ int met2_fit_strided(met2_plan *plan, int32_t method, int64_t nvox, const double
  * H2D of the next chunk of a volume, this fit, D2H of the previous chunk's outputs, on separate streams (motor:167-182,
  * :427-503 are that loop in the reference, one image row at a time) -- enqueues chunk after chunk and calls met2_plan_finish
  * once: it waits for `stream` and returns MET2_E_INVALID if any fit enqueued since the last finish saw such an index.
- * One plan serves one stream at a time (its sort scratch is per plan). */
+ * One plan serves one stream at a time (its sort scratch is per plan): enqueueing on, or finishing, another stream while fits are pending
+ * returns MET2_E_STATE. */
 int met2_fit_enqueue_strided(met2_plan *plan, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
                              int64_t echo_stride, const double *fa_index, const uint8_t *mask, double *fsol, double *sig,
                              double *reg, double *lam, double *maps, int32_t *status, void *stream);

@@ -830,7 +830,9 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
                         const double tl = A.blam[ev];              //  lambda_j is formed on the host, and B + lambda K does not care about an ulp)
                         if (fabs(x - tl) <= 1e-14 * tl) {
                             const double *rec = A.btab + ((size_t)fa * A.nbtab + ev) * A.btab_stride;
-                            tab.U0 = rec; tab.logdet0 = rec[A.btab_stride - 1];
+                            const double ld0 = rec[A.btab_stride - 1];
+                            if (fabs(ld0) <= 1.79769313486231570815e308) { tab.U0 = rec; tab.logdet0 = ld0; }      // (nan: the table's factorisation failed --
+                                                                                                                    //  the voxel factorises itself and reports its own failure)
                         }
                     }
                     ++ev;
@@ -1529,6 +1531,7 @@ struct met2_plan {
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
     int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
     bool err_pending = false;
+    hipStream_t err_stream = nullptr;                     // the stream the fits since the last finish were enqueued on (one plan serves one stream at a time)
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     bool timed = false, timed2 = false;
@@ -2268,6 +2271,8 @@ int met2_plan_finish(met2_plan *p, void *stream)
 {
     if (!p) return fail(MET2_E_INVALID, "NULL plan");
     USE_DEVICE(p->opt.device);
+    if (p->err_pending && p->err_stream != (hipStream_t)stream)
+        return fail(MET2_E_STATE, "met2_plan_finish on another stream than the one the plan's fits were enqueued on");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (p->err_pending) {
         p->err_pending = false;
@@ -2297,6 +2302,8 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     if (nvox == 0) return MET2_OK;
     USE_DEVICE(p->opt.device);
     hipStream_t s = (hipStream_t)stream;
+    if (p->err_pending && p->err_stream != s)
+        return fail(MET2_E_STATE, "fits are pending on another stream of this plan: call met2_plan_finish on it first (one plan serves one stream at a time)");
     int rc = ensure_sort_bufs(p, nvox);
     if (rc) return rc;
     // capacity scheme: pass 1 with a passive-set capacity kfast < n (more waves per CU), pass 2 with the full
@@ -2459,7 +2466,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     // FA index range errors (IndexError in the reference): the error word lands in the plan's pinned host word; the blocking entries
     // wait for it here, an enqueued fit leaves it to met2_plan_finish (errors of several enqueued fits accumulate: the kernel ORs)
     HIPCHK(hipMemcpyAsync(p->hErr, sb.err, sizeof(int), hipMemcpyDeviceToHost, s));
-    p->err_pending = true;
+    p->err_pending = true; p->err_stream = s;
     if (!sync) return MET2_OK;
     return met2_plan_finish(p, stream);
 }
@@ -2503,11 +2510,24 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     const bool gemm = p->n_fa >= 8 && tuning_env("MET2_FA_GEMM", 0, 1, 1) != 0;
     int64_t pass = nvox;
     if (gemm) {
-        const int64_t budget = (int64_t)6 << 30;                                   // bytes of scratch
+        // scratch: at most 6 GiB and at most a quarter of what the device has free right now (several plans or ranks may share it);
+        // a failed allocation halves the pass instead of failing the call
+        size_t mem_free = 0, mem_total = 0;
+        HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+        const int64_t budget = std::min<int64_t>((int64_t)6 << 30, (int64_t)(mem_free / 4) + (int64_t)sizeof(double) * p->cap_h);
         pass = std::max<int64_t>(32, std::min<int64_t>(nvox, (budget / (8 * Mh)) & ~(int64_t)31));
+        if (p->cap_h >= 32 * Mh && p->cap_h < pass * Mh && p->cap_h >= std::min<int64_t>(nvox, 65536) * Mh)
+            pass = (p->cap_h / Mh) & ~(int64_t)31;                                  // what the plan already holds serves 64 Ki voxels a pass: keep it
         if (p->cap_h < pass * Mh) {
             if (p->dH) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(p->dH)); p->dH = nullptr; p->cap_h = 0; }
-            HIPCHK(hipMalloc(&p->dH, sizeof(double) * (size_t)(pass * Mh)));
+            for (;;) {
+                const hipError_t e = hipMalloc(&p->dH, sizeof(double) * (size_t)(pass * Mh));
+                if (e == hipSuccess) break;
+                (void)hipGetLastError();
+                p->dH = nullptr;
+                if (pass <= 32) return fail(MET2_E_HIP, std::string("hipMalloc of the FA walk's scratch: ") + hipGetErrorString(e));
+                pass = std::max<int64_t>(32, (pass / 2) & ~(int64_t)31);
+            }
             p->cap_h = pass * Mh;
         }
     }

@@ -193,56 +193,68 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                     d_mv[k][:n].copy_(mv_h[lo:hi], non_blocking=True)
                 ev_in[k].record(s_in)
 
-        upload(0)
-        for c in range(nch):
-            k = c & 1
-            lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
-            n = hi - lo
+        try:
+            upload(0)
+            for c in range(nch):
+                k = c & 1
+                lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
+                n = hi - lo
+                with torch.cuda.stream(s_fit):
+                    s_fit.wait_event(ev_in[k])
+                    if c >= 2:
+                        s_fit.wait_event(ev_out[k])     # the outputs of chunk c - 2 have left this slot
+                    o = d_out[k]
+                    raw = cut(d_in[k], n)
+                    if mv_h is not None:                # motor:180-182, :279 on the device, in place
+                        raw.mul_(d_mv[k][:n].unsqueeze(0) if echo_major else d_mv[k][:n].unsqueeze(1))
+                        raw.clamp_(min=0.0)
+                    dd = raw.t() if echo_major else raw # [n, n_te] either way (echo-major: a strided view, read in place when the chunk is full)
+                    mk = None if mk_h is None else d_mk[k][:n]
+                    gate = dd.sum(dim=1) > 0
+                    d_gate[k][:n].copy_(gate if mk is None else (gate & (mk != 0)))
+                    if fa_method == "brute-force":
+                        fa, _, _ = plan.fa_bruteforce(dd, mk)
+                        d_fa[k][:n].copy_(fa)
+                    elif callable(fa_method):
+                        d_fa[k][:n].copy_(fa_method(dd, mk))
+                    elif fa_h is None:
+                        d_fa[k][:n].zero_()
+                    # the chunk's maps are [6, n]: a contiguous [6 * n] prefix of the slot's buffer viewed as [6, n]
+                    maps_v = o["maps"].reshape(-1)[: 6 * n].view(6, n)
+                    plan.fit(reg_method, dd, fa_index=d_fa[k][:n], mask=mk, sync=False,
+                             out={"fsol": o["fsol"][:n], "sig": o["sig"][:n], "reg": o["reg"][:n], "lam": o["lam"][:n], "maps": maps_v, "status": o["status"][:n]},
+                             want_lambda=True)
+                    ev_fit[k].record(s_fit)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(ev_fit[k])
+                    res["fsol"][lo:hi].copy_(o["fsol"][:n], non_blocking=True)
+                    res["sig"][lo:hi].copy_(o["sig"][:n], non_blocking=True)
+                    res["reg"][lo:hi].copy_(o["reg"][:n], non_blocking=True)
+                    res["status"][lo:hi].copy_(o["status"][:n], non_blocking=True)
+                    res["fa_index"][lo:hi].copy_(d_fa[k][:n], non_blocking=True)
+                    res["fa_gate"][lo:hi].copy_(d_gate[k][:n], non_blocking=True)
+                    if want_lambda:
+                        res["lam"][lo:hi].copy_(o["lam"][:n], non_blocking=True)
+                    for i in range(6):
+                        res["maps"][i, lo:hi].copy_(maps_v[i], non_blocking=True)
+                    ev_out[k].record(s_out)
+                if c + 1 < nch:
+                    upload(c + 1)                       # staged and enqueued while the GPU works on chunk c
             with torch.cuda.stream(s_fit):
-                s_fit.wait_event(ev_in[k])
-                if c >= 2:
-                    s_fit.wait_event(ev_out[k])     # the outputs of chunk c - 2 have left this slot
-                o = d_out[k]
-                raw = cut(d_in[k], n)
-                if mv_h is not None:                # motor:180-182, :279 on the device, in place
-                    raw.mul_(d_mv[k][:n].unsqueeze(0) if echo_major else d_mv[k][:n].unsqueeze(1))
-                    raw.clamp_(min=0.0)
-                dd = raw.t() if echo_major else raw # [n, n_te] either way (echo-major: a strided view, read in place when the chunk is full)
-                mk = None if mk_h is None else d_mk[k][:n]
-                gate = dd.sum(dim=1) > 0
-                d_gate[k][:n].copy_(gate if mk is None else (gate & (mk != 0)))
-                if fa_method == "brute-force":
-                    fa, _, _ = plan.fa_bruteforce(dd, mk)
-                    d_fa[k][:n].copy_(fa)
-                elif callable(fa_method):
-                    d_fa[k][:n].copy_(fa_method(dd, mk))
-                elif fa_h is None:
-                    d_fa[k][:n].zero_()
-                # the chunk's maps are [6, n]: a contiguous [6 * n] prefix of the slot's buffer viewed as [6, n]
-                maps_v = o["maps"].reshape(-1)[: 6 * n].view(6, n)
-                plan.fit(reg_method, dd, fa_index=d_fa[k][:n], mask=mk, sync=False,
-                         out={"fsol": o["fsol"][:n], "sig": o["sig"][:n], "reg": o["reg"][:n], "lam": o["lam"][:n], "maps": maps_v, "status": o["status"][:n]},
-                         want_lambda=True)
-                ev_fit[k].record(s_fit)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_fit[k])
-                res["fsol"][lo:hi].copy_(o["fsol"][:n], non_blocking=True)
-                res["sig"][lo:hi].copy_(o["sig"][:n], non_blocking=True)
-                res["reg"][lo:hi].copy_(o["reg"][:n], non_blocking=True)
-                res["status"][lo:hi].copy_(o["status"][:n], non_blocking=True)
-                res["fa_index"][lo:hi].copy_(d_fa[k][:n], non_blocking=True)
-                res["fa_gate"][lo:hi].copy_(d_gate[k][:n], non_blocking=True)
-                if want_lambda:
-                    res["lam"][lo:hi].copy_(o["lam"][:n], non_blocking=True)
-                for i in range(6):
-                    res["maps"][i, lo:hi].copy_(maps_v[i], non_blocking=True)
-                ev_out[k].record(s_out)
-            if c + 1 < nch:
-                upload(c + 1)                       # staged and enqueued while the GPU works on chunk c
-        with torch.cuda.stream(s_fit):
-            plan.finish()
-        s_out.synchronize()
-        torch.cuda.current_stream(dev).wait_stream(s_fit)
+                plan.finish()
+            s_out.synchronize()
+            torch.cuda.current_stream(dev).wait_stream(s_fit)
+        except BaseException:
+            # the device buffers of this frame go back to the caching allocator as it unwinds: nothing may still be in flight on them
+            # (copies on s_out, fits enqueued before a later plan.fit raised), and the plan must not keep a pending error word
+            for st_ in (s_in, s_fit, s_out):
+                st_.synchronize()
+            try:
+                with torch.cuda.stream(s_fit):
+                    plan.finish()
+            except Exception:
+                pass
+            raise
     return res
 
 

@@ -156,11 +156,17 @@ def test_hip_vs_reference_8192_x2_voxels_at_48x120(tail_x2_s2):
 @pytest.mark.gpu
 def test_bench_two_ranks_share_the_gpu_with_the_hip_fit():
     # the launcher end to end on the one-GPU box: two ranks, both on cuda:0, gloo for the collective, the HIP fit as compute
-    p, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--dims", "16,16,8", "--gather", "all", "--cpu-seconds", "1", "--no-end-to-end"],
+    # (N > 1 skips rank 0's CPU baseline unless asked: --cpu-baseline brings the parity block back)
+    p, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--dims", "16,16,8", "--gather", "all", "--cpu-seconds", "1", "--cpu-baseline"],
                          {"MET2_BENCH_SHARE_GPU": "1", "MET2_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["config"]["gather_bytes_per_voxel"] == 792
     assert line["value"] > 0 and line["parity"]["frac_over_1e-5"] <= 0.002
+    assert "end_to_end" not in line                                   # rank 0's host-to-host leg is a single-GPU report
+    mg = line["multi_gpu"]                                            # per-rank kernel times and BOTH payloads of the collective in the one run
+    assert len(mg["kernel_ms_per_rank"]) == 2 and mg["kernel_ms_min"] > 0 and mg["kernel_ms_max"] >= mg["kernel_ms_min"]
+    assert mg["gather_ms"]["maps"]["bytes_per_voxel"] == 56 and mg["gather_ms"]["all"]["bytes_per_voxel"] == 792
+    assert mg["gather_ms"]["all"]["ms_max_over_ranks"] > 0 and len(mg["gather_ms_in_timed_steps_per_rank"]) == 2
 
 
 _RCCL_WORKER = r"""

@@ -194,3 +194,127 @@ def test_full_size_properties_config_4(pkg):
     o2 = plan.fit("GCV", data[perm], fa_index=fa2, want_lambda=True)
     assert torch.equal(o2["fsol"], out["fsol"][perm]) and torch.equal(o2["lam"], lam[perm]) and torch.equal(o2["maps"], out["maps"][:, perm])
     plan.close()
+
+
+# ---- the boundary: concurrency contract, stream guard, clean-up pass at one bin per lane ---------------------------------------
+@gpu
+def test_two_host_threads_two_plans_run_concurrently(pkg):
+    """SURVEY section 8b item 5 as the header states it: no global state, one plan per host thread, all at once.  Two threads, each
+    with its own plan and its own stream on cuda:0, fit different volumes with different methods at the same time (ctypes releases
+    the GIL inside the calls); the results are those of the same fits run one after the other, bit for bit."""
+    import threading
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2 = 32, 60
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    jobs = [("X2", "L2", 11), ("BayesReg", "I", 12)]
+    plans, datas, want = [], [], []
+    for meth, pen, seed in jobs:
+        pl = pkg.Met2Plan(nte, nt2, 1)
+        pl.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty(pen, T2s)
+        d, _, _ = synth.make_voxels(60_000, nte=nte, seed=seed, device="cuda")
+        plans.append(pl); datas.append(d); want.append(pl.fit(meth, d, want_lambda=True))
+    torch.cuda.synchronize()
+    got = [None, None]; errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    got[i] = plans[i].fit(jobs[i][0], datas[i], want_lambda=True)
+            st.synchronize()
+        except Exception as e:          # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for i in range(2):
+        for k in ("fsol", "sig", "reg", "lam", "maps", "status"):
+            assert torch.equal(got[i][k], want[i][k]), (jobs[i], k)
+    for pl in plans:
+        pl.close()
+
+
+@gpu
+def test_a_plan_serves_one_stream_at_a_time(pkg):
+    """Fits enqueued on one stream and not yet finished: a fit or a finish on ANOTHER stream of the same plan is refused (MET2_E_STATE)
+    instead of racing on the plan's sort scratch and error word; finishing on the right stream clears it."""
+    import torch
+    L = importlib.import_module(PKG + "._lib")
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2 = 32, 60
+    T2s = synth.t2_grid(nt2)
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, 1000.0 * np.ones(nt2), 10.0, np.array([150.0]), 3000.0).set_penalty("L2", T2s)
+    data, _, _ = synth.make_voxels(4096, nte=nte, seed=2, device="cuda")
+    ref = plan.fit("X2", data)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        s1.wait_stream(torch.cuda.current_stream())
+        a = plan.fit("X2", data, sync=False)
+    with torch.cuda.stream(s2):
+        with pytest.raises(L.Met2Error, match="another stream"):
+            plan.fit("X2", data, sync=False)
+        with pytest.raises(L.Met2Error, match="another stream"):
+            plan.finish()
+    with torch.cuda.stream(s1):
+        plan.finish()
+    assert torch.equal(a["fsol"], ref["fsol"])
+    with torch.cuda.stream(s2):                                       # nothing pending any more: any stream will do
+        b = plan.fit("X2", data)
+    assert torch.equal(b["fsol"], ref["fsol"])
+    plan.close()
+
+
+@gpu
+@pytest.mark.parametrize("method", ["X2", "L_curve", "T2SPARC"])
+def test_capacity_overflow_and_clean_up_pass_at_one_bin_per_lane(pkg, method):
+    """nT2 = 60: the first pass runs with a passive-set capacity of 50 bins.  Voxels whose regularised solution is positive on the whole
+    grid (a flat spectrum pushed through the dictionary; at the large lambdas every search visits, the L2-smoothed solution is broad)
+    must hit that capacity, leave the pass, be re-queued and solved at full capacity: same answer as the oracle, no
+    MET2_ST_KOVERFLOW left, and a clean-up pass that really ran."""
+    import torch
+    from oracle import oracle
+    oracle.build()
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2, nvox = 32, 60, 600
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty("L2", T2s)
+    D = np.ascontiguousarray(np.transpose(plan.get_dictionary(), (2, 0, 1)))
+    rng = np.random.default_rng(8)
+    spec = 1.0 + 0.2 * rng.uniform(size=(nvox, nt2))                  # broad: every bin carries signal
+    sig = spec @ D[0].T
+    d = np.abs(sig * (1.0 + 1e-2 * rng.standard_normal(sig.shape)))
+    data = torch.as_tensor(d, device="cuda")
+    out = plan.fit(method, data, want_lambda=True)
+    st = out["status"].cpu().numpy()
+    assert (st & 1).all() and not (st & 32).any()
+    assert plan.last_second_pass_ms() > 0.0
+    Lm = oracle.penalty(nt2, "L2", T2s)
+    fs, sg, rg, so = oracle.fit_batch(method, D, Lm, d, np.zeros(nvox), np.ones(nvox), lambda_reg=synth.lambda_grid(), nthreads=8)
+    got = out["fsol"].cpu().numpy()
+    k_final = (got > 0).sum(axis=1)
+    e = np.max(np.abs(got - fs), axis=1) / np.max(np.abs(fs), axis=1)
+    print("MEASURED overflow %s: final support %d..%d bins, n_over=%d of %d, max %.2e" % (method, k_final.min(), k_final.max(), int((e >= 1e-5).sum()), nvox, e.max()))
+    if method == "X2":
+        # these spectra fit the data almost exactly (SSE_0 is ~30 x smaller than for a two-peak voxel), so Brent's accept/reject ties are
+        # that much more frequent than DESIGN section 2's 5e-5: what must hold for EVERY voxel is that it carries the exact solution of
+        # its own lambda with the chi-square ratio on target
+        lam = out["lam"].cpu().numpy(); reg = out["reg"].cpu().numpy()
+        worst = 0.0
+        for v in range(0, nvox, 7):
+            x_at = oracle.nnls_tik(D[0], d[v] / d[v, 0], Lm, lam[v]) * d[v, 0]
+            worst = max(worst, np.max(np.abs(x_at - got[v])) / np.max(np.abs(got[v])))
+        same = e < 1e-5
+        print("MEASURED overflow X2: exact solution at the voxel's own lambda to %.1e; max |k_est - oracle's| where the spectra agree %.1e" % (worst, np.abs(reg - rg)[same].max()))
+        # measured: 8 of 600 beyond 1e-5 (max 3.3e-5), exact at their own lambda to 5.6e-10
+        assert worst < 1e-8 and (~same).mean() < 0.05 and np.abs(reg - rg)[same].max() < 2e-5
+    else:
+        assert (e >= 1e-5).sum() == 0, (method, int((e >= 1e-5).sum()), e.max())
+    if method == "T2SPARC":
+        assert k_final.max() > 50                                     # the set that overflowed the first pass is the answer itself
+    plan.close()
