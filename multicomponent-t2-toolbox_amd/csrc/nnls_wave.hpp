@@ -1345,6 +1345,58 @@ __device__ __forceinline__ double sse_of(const WaveShared &S, const NnlsState<NB
     return out;
 }
 
+template <int NB>
+__device__ __forceinline__ void project(const WaveShared &S, double bvec, int lane, double (&h)[NB]);
+
+// One step of iterative refinement of the passive sub-problem with the residual taken from D itself (corrected semi-normal equations):
+//     g = D^T (b - D x) - lam K x,    R^T R delta = g_P,    x_P += delta.
+// The Gram-form solve leaves x with a relative error of ~cond(G_PP) eps (1e-10 .. 1e-8: B = D^T D is itself a rounded matrix); the
+// correction computed from D brings it to the level of a QR solve of the augmented system (~cond(D_P) eps), which is what the
+// reference's Lawson-Hanson works at.  Called only where a Brent comparison sits inside the Gram-form noise (fminbound_tie_dev): a plain,
+// unpipelined forward substitution is good enough.
+template <int NB>
+__device__ __forceinline__ void refine_csne(const WaveShared &S, NnlsState<NB> &st, double lam, double bvec, int lane)
+{
+    const int k = st.k;
+    if (k == 0) return;
+    double r = bvec - model_signal<NB>(S, st, lane);
+    r = (lane < S.m) ? r : 0.0;
+    double g[NB];
+    project<NB>(S, r, lane, g);                                        // D^T (b - D x), bin-indexed
+    if (lam != 0.0) {
+        double kbl[NB][5], kx[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) kbl[b][d] = S.kband[d * 128 + lane + 64 * b];
+        band_mul<NB>(kbl, st.x, lane, kx);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) g[b] = fma(-lam, kx[b], g[b]);
+    }
+    double u[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { const double t = gatherN<NB>(g, st.ord[b]); u[b] = (lane + 64 * b < k) ? t : 0.0; }      // by position
+    for (int i = 0; i + 1 < k; ++i) {                                  // R^T u = g_P: row i of R is entry i of every later column
+        double t[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) t[b] = u[b] * st.rinv[b];
+        const double si = bcastN<NB>(t, i);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; if (pl > i && pl < k) u[b] = fma(-S.R[col_base(pl) + i], si, u[b]); }
+    }
+    double ysave[NB], dl[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { ysave[b] = st.y[b]; st.y[b] = (lane + 64 * b < k) ? u[b] * st.rinv[b] : 0.0; }
+    back_subst<NB>(S, st, lane, dl);                                   // R delta = u
+#pragma unroll
+    for (int b = 0; b < NB; ++b) st.y[b] = ysave[b];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double d = gatherN<NB>(dl, max(st.pos[b], 0));           // by bin
+        if (st.pos[b] >= 0) st.x[b] += d;
+    }
+}
+
 // h = D^T b for the bins a lane owns (bvec: lane e holds echo e)
 template <int NB>
 __device__ __forceinline__ void project(const WaveShared &S, double bvec, int lane, double (&h)[NB])

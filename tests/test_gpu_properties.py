@@ -227,9 +227,21 @@ def test_odd_shapes_vs_oracle(pkg, nte, nt2):
         es = np.max(np.abs(gs - sg), axis=1) / np.max(np.abs(sg), axis=1)
         # the fitted signal is unique even where a near-degenerate dictionary (tiny nTE) leaves the spectrum loose
         print("MEASURED odd %s %dx%d n_over fsol=%d sig=%d of %d max %.2e %.2e" % (meth, nte, nt2, int((e >= 1e-5).sum()), int((es >= 1e-5).sum()), nvox, e.max(), es.max()))
-        # measured over the eight shapes: fsol max 6.0e-8, signal max 1.3e-9, no voxel of 300 over 1e-5
-        assert es.max() < 1e-7, (meth, nte, nt2, es.max())
-        assert e.max() < 2e-6, (meth, nte, nt2, e.max())
+        # measured over the eight shapes: fsol max 6.0e-8, signal max 1.3e-9.  X2 since round 4 (tie guard: near-ties of Brent's search are
+        # decided on refined objective values, which is where the REFERENCE sides with neither solver predictably): a voxel may take the
+        # other branch of such a tie than the oracle does (1 of 2 400 over these shapes) -- it must then sit inside Brent's own tolerance
+        # interval of the oracle's lambda and carry the exact solution of its own lambda
+        tie = np.zeros(nvox, dtype=bool)
+        if meth == "X2":
+            lam_h = out["lam"].cpu().numpy()
+            lam_o = oracle.fit_batch(meth, D, L, d, f, ones, nthreads=8, want_lambda=True)[4]
+            for v in np.nonzero(e >= 2e-6)[0]:
+                x_at = oracle.nnls_tik(D[int(f[v])], d[v] / d[v, 0], L, lam_h[v]) * d[v, 0]
+                assert abs(lam_h[v] - lam_o[v]) <= 1e-5 and np.max(np.abs(x_at - got[v])) / np.max(np.abs(got[v])) < 1e-8, (nte, nt2, v, lam_h[v], lam_o[v])
+                tie[v] = True
+            assert tie.sum() <= 1, (nte, nt2, int(tie.sum()))
+        assert es[~tie].max() < 1e-7, (meth, nte, nt2, es.max())
+        assert e[~tie].max() < 2e-6, (meth, nte, nt2, e.max())
         assert (out["status"].cpu().numpy() & 1).all()
     idx, km, sse, ff, rs = oracle.fa_bruteforce(D, d, ones, nthreads=8, want_resid=True)
     fa_g, km_g, resid = plan.fa_bruteforce(data, None, want_resid=True)
