@@ -121,7 +121,8 @@ __global__ void relayout_kernel(int nte, int nt2, int nfa, const double *__restr
 // remainder R (m x n) lives in LDS, lane <-> column for the sweeps over columns, lane <-> echo for the basis vectors.
 // ------------------------------------------------------------------------------------------
 #define MET2_GCV_LR_TOL 1e-9
-__global__ __launch_bounds__(64) void gcv_basis_kernel(int m, int n, const double *__restrict__ D, double *__restrict__ Aq, double *__restrict__ res)
+__global__ __launch_bounds__(64) void gcv_basis_kernel(int m, int n, const double *__restrict__ D, double *__restrict__ Aq, double *__restrict__ Qt,
+                                                       double *__restrict__ res)
 {
     extern __shared__ double basis_lds[];
     double *R = basis_lds, *Q = basis_lds + (size_t)m * n;             // R[m][n], Q[16][64]
@@ -163,6 +164,9 @@ __global__ __launch_bounds__(64) void gcv_basis_kernel(int m, int n, const doubl
             for (int e = 0; e < m; ++e) a = fma(Q[s * 64 + e], Df[e * n + j], a);
             Aq[((size_t)fa * n + j) * MET2_GCV_LR_RANK + s] = a;
         }
+    // the basis itself, one vector per row ([fa][16][m]): the FA walk's lower bounds project the voxel's signal on it (fa_kernel)
+    for (int s = 0; s < MET2_GCV_LR_RANK; ++s)
+        if (lane < m) Qt[((size_t)fa * MET2_GCV_LR_RANK + s) * m + lane] = Q[s * 64 + lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1066,6 +1070,8 @@ struct FaArgs {
     double *fa_index, *km, *resid;
     int *queue;
     int64_t nvox;
+    double *Hq;               // [nvox of this pass][nfa * 16]: Q_fa^T b in every flip angle's low-rank basis (fa_project_kernel on the stacked bases), or NULL: no pruning.
+                              // The walk overwrites entry [fa * 16] with the angle's lower bound (a voxel's row belongs to the one wave that walks it).
     const double *H;          // [nvox of this pass][nfa * n]: h = D_fa^T b of every flip angle (fa_project_kernel), or NULL: formed in the walk
     int64_t v0;               // first voxel of this pass (H row 0), voxels [v0, v0 + nvox_pass)
     int64_t v_end;            // one past the last voxel of this pass
@@ -1181,23 +1187,57 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             act[vv] = mk && fin && (sum > 0.0);
             best_r[vv] = INFINITY; best_km[vv] = 0.0; best_fa[vv] = 0;
         }
-        for (int fa = 0; fa < A.nfa; ++fa) {
-            const double *Bf = A.Bfa + (size_t)fa * n * n;
-            S.B = Bf; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
+        // Lower bounds (A.Hq): the NNLS residual of a flip angle is at least the unconstrained least-squares residual on its dictionary's
+        // column space, ||b||^2 - ||Q_fa^T b||^2 in the plan's low-rank basis (exact to 1e-18 ||b||^2 while the basis leaves < 1e-9 of D).
+        // The angle with the smallest bound is solved first (round -1); in rounds 0 .. nfa - 1 an angle whose bound exceeds the best
+        // residual found so far cannot be the argmin and is skipped -- on the reference's recipe 28 of 91 angles per voxel are solved
+        // (median 24).  Lane f (and f + 64) forms the bound of angle f and parks it in the voxel's own row of Hq (no registers held
+        // through the walk).
+        double slack[VPW];
+        int fa0[VPW];
+        u64 cand[VPW][2];                      // flip angles whose bound does not exceed the best residual so far (wave-uniform masks; all ones: no pruning)
+        // the masks are formed again whenever the best residual improves: lane f compares its angle's parked bound
+        auto candidates = [&](int vv) {
+            const double thr = fma(best_r[vv] * best_r[vv], 1.0 + 1e-6, slack[vv]);
+            const double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) { const int j = min(lane + 64 * bb, n - 1); S.bdiag[bb] = Bf[(size_t)j * n + j]; }
+            for (int sl = 0; sl < 2; ++sl) {
+                const int f = lane + 64 * sl;
+                const double lb = q[(size_t)min(f, A.nfa - 1) * MET2_GCV_LR_RANK];
+                cand[vv][sl] = ballot(f < A.nfa && !(lb > thr));
+            }
+        };
+#pragma unroll
+        for (int vv = 0; vv < VPW; ++vv) {
+            slack[vv] = 0.0; fa0[vv] = -1; cand[vv][0] = cand[vv][1] = ~0ull;
+            if (A.Hq && act[vv]) {
+                const double bb2 = wave_sum(b[vv] * b[vv]);
+                double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
+                double l2[2];
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int f = lane + 64 * sl;
+                    double cs = 0.0;
+                    if (f < A.nfa)
+                        for (int j = 0; j < MET2_GCV_LR_RANK; ++j) { const double c = q[(size_t)f * MET2_GCV_LR_RANK + j]; cs = fma(c, c, cs); }
+                    l2[sl] = (f < A.nfa) ? bb2 - cs : INFINITY;
+                    if (f < A.nfa) q[(size_t)f * MET2_GCV_LR_RANK] = l2[sl];
+                }
+                slack[vv] = 1e-13 * bb2;                                  // rounding of the difference above
+                const double mn = wave_min(fmin(l2[0], l2[1]));
+                const u64 m0 = ballot(l2[0] == mn), m1 = ballot(l2[1] == mn);
+                fa0[vv] = m0 ? first_lane(m0) : 64 + first_lane(m1);
+            }
+        }
+        for (int i = A.Hq ? -1 : 0; i < A.nfa; ++i) {
 #ifdef MET2_CYCSTATS
             const unsigned long long cv0 = __builtin_readcyclecounter();
 #endif
-            if (A.H) {                         // h of this flip angle from the batched MFMA contraction: one contiguous row per voxel
+            if (!A.H) {                        // few flip angles: no batched contraction; rows of D come from L2, each loaded once for all the wave's voxels
+                const double *Bf = A.Bfa + (size_t)i * n * n;
+                S.B = Bf; S.D = A.Dfa + (size_t)i * m * n; S.Dt = A.Dtfa + (size_t)i * m * n;
 #pragma unroll
-                for (int vv = 0; vv < VPW; ++vv) {
-                    const int64_t vr = min(v0 + vv, A.v_end - 1) - A.v0;
-                    const double *hrow = A.H + (size_t)vr * Mh + (size_t)fa * n;
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) { const int j = lane + 64 * bb; const double hv = hrow[min(j, n - 1)]; st[vv].h[bb] = (j < n) ? hv : 0.0; }
-                }
-            } else {                           // rows of D come from L2: load each once for all the wave's voxels
+                for (int bb = 0; bb < NB; ++bb) { const int j = min(lane + 64 * bb, n - 1); S.bdiag[bb] = Bf[(size_t)j * n + j]; }
                 double hh[VPW][NB];
                 project_multi<NB, VPW>(S, b, lane, hh);
 #pragma unroll
@@ -1207,16 +1247,28 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             }
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
-                if (!act[vv]) continue;
+                const int fa = (i < 0) ? fa0[vv] : i;
+                if (!act[vv] || fa < 0 || (i >= 0 && fa == fa0[vv])) continue;
+                if (!((cand[vv][fa >> 6] >> (fa & 63)) & 1ull)) continue;            // its lower bound exceeds the best residual: cannot be the argmin
+                if (A.H) {                     // h of this flip angle from the batched MFMA contraction: one contiguous row per voxel
+                    const double *Bf = A.Bfa + (size_t)fa * n * n;
+                    S.B = Bf; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) { const int j = min(lane + 64 * bb, n - 1); S.bdiag[bb] = Bf[(size_t)j * n + j]; }
+                    const double *hrow = A.H + (size_t)(v0 + vv - A.v0) * Mh + (size_t)fa * n;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) { const int j = lane + 64 * bb; const double hv = hrow[min(j, n - 1)]; st[vv].h[bb] = (j < n) ? hv : 0.0; }
+                }
                 nnls_solve_warm<NB, (NB == 2 && VPW == 1)>(S, bd, st[vv], 0.0, false, lane);   // one position slot (k <= nTE); with two voxels per wave the second code path stops the voxel loop from unrolling
                 const double rn = sqrt(sse_of<NB>(S, st[vv], b[vv], lane));
                 if (A.resid && lane == 0) A.resid[(size_t)(v0 + vv) * A.nfa + fa] = rn;
-                if (rn < best_r[vv]) {        // np.argmin: first minimum wins
+                if (rn < best_r[vv] || (rn == best_r[vv] && fa < best_fa[vv])) {      // np.argmin: the first minimum wins, whatever order the angles are visited in
                     best_r[vv] = rn; best_fa[vv] = fa;
                     double t = 0.0;
 #pragma unroll
                     for (int bb = 0; bb < NB; ++bb) t += (lane + 64 * bb < n) ? st[vv].x[bb] : 0.0;
                     best_km[vv] = wave_sum(t);
+                    if (A.Hq) candidates(vv);
                 }
             }
 #ifdef MET2_CYCSTATS
@@ -1662,6 +1714,7 @@ struct met2_plan {
                                                           // flip angle 0): only then is the seeded start the cold start's solution
     double *dH = nullptr; int64_t cap_h = 0;              // FA walk: h of every flip angle for one pass of voxels (fa_project_kernel), grown on demand
     double *dBtab = nullptr; int btab_stride = 0;         // BayesReg factor tables [nfa][MET2_BAYES_TABLE][btab_stride] (built with the seeds)
+    double *dQt = nullptr;                                // [nfa][16][n_te]: the basis vectors themselves (lower bounds of the brute-force FA search)
     double *dAq = nullptr, *dAqRes = nullptr;             // GCV: [nfa][n_t2][16] = (Q^T D)^T in the flip angle's low-rank basis, [nfa] what the basis leaves of D
     double gcv_res = 0.0;                                 // the largest of dAqRes
     bool gcv_lr = false;                                  // every flip angle's dictionary is of numerical rank <= 16: the GCV trace takes the 17 x 17 form
@@ -2161,6 +2214,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dDt, sizeof(double) * (size_t)n_fa * n_te * n_t2));
     HIPCHK(hipMalloc(&p->dAq, sizeof(double) * (size_t)n_fa * n_t2 * MET2_GCV_LR_RANK));
     HIPCHK(hipMalloc(&p->dAqRes, sizeof(double) * (size_t)n_fa));
+    HIPCHK(hipMalloc(&p->dQt, sizeof(double) * (size_t)n_fa * MET2_GCV_LR_RANK * n_te));
     HIPCHK(hipMalloc(&p->dKband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dLband, sizeof(double) * 5 * 128));
     HIPCHK(hipMalloc(&p->dKd, sizeof(double) * (size_t)n_t2 * n_t2));
@@ -2199,7 +2253,7 @@ int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
+    void *bufs[] = {p->dQt, p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -2216,7 +2270,7 @@ static int build_gram(met2_plan *p, hipStream_t s)
     HIPCHK(hipGetLastError());
     const int lds = (int)sizeof(double) * (p->n_te * p->n_t2 + MET2_GCV_LR_RANK * 64);
     HIPCHK(hipFuncSetAttribute((const void *)gcv_basis_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gcv_basis_kernel, dim3(p->n_fa), dim3(64), lds, s, p->n_te, p->n_t2, p->dD, p->dAq, p->dAqRes);
+    hipLaunchKernelGGL(gcv_basis_kernel, dim3(p->n_fa), dim3(64), lds, s, p->n_te, p->n_t2, p->dD, p->dAq, p->dQt, p->dAqRes);
     HIPCHK(hipGetLastError());
     std::vector<double> res(p->n_fa);
     HIPCHK(hipMemcpyAsync(res.data(), p->dAqRes, sizeof(double) * p->n_fa, hipMemcpyDeviceToHost, s));
@@ -2644,7 +2698,12 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     A.queue = sb.queue; A.nvox = nvox;
     // h = D_fa^T b of all flip angles by one MFMA GEMM per pass of voxels (fa_project_kernel) when the plan has more than a handful
     // of flip angles; the pass size bounds the scratch (8 nfa n bytes per voxel: 87 KB at 91 x 120)
-    const int64_t Mh = (int64_t)p->n_fa * p->n_t2;
+    // Mh: doubles of H per voxel -- h of every flip angle, and behind it (when the walk prunes) the 16 coefficients of the voxel in every
+    // flip angle's low-rank basis.  Pruning needs the basis to span the dictionary (p->gcv_lr), all residuals NOT to be asked for, and the
+    // bounds of all angles to fit two per lane; MET2_FA_NOPRUNE=1: test switch.
+    const bool prune = p->gcv_lr && !resid && p->n_fa >= 8 && p->n_fa <= 128 && !getenv("MET2_FA_NOPRUNE");      // (<= 128: the bounds are formed two per lane)
+    const int64_t Mh0 = (int64_t)p->n_fa * p->n_t2;
+    const int64_t Mh = Mh0 + (prune ? (int64_t)p->n_fa * MET2_GCV_LR_RANK : 0);
     const bool gemm = p->n_fa >= 8 && tuning_env("MET2_FA_GEMM", 0, 1, 1) != 0;
     int64_t pass = nvox;
     if (gemm) {
@@ -2676,7 +2735,7 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
         hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES>), dim3(g.grid), dim3(g.block), g.lds, s, A);                       \
     } while (0)
     for (int64_t v0 = 0; v0 < nvox; v0 += pass) {
-        A.v0 = v0; A.v_end = std::min<int64_t>(nvox, v0 + pass); A.H = nullptr;
+        A.v0 = v0; A.v_end = std::min<int64_t>(nvox, v0 + pass); A.H = nullptr; A.Hq = nullptr;
         HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
         if (gemm) {
             FaGemmArgs G;
@@ -2688,6 +2747,13 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
             if (ks <= 8)       hipLaunchKernelGGL(fa_project_kernel<8>, grid, block, 0, s, G);
             else if (ks <= 12) hipLaunchKernelGGL(fa_project_kernel<12>, grid, block, 0, s, G);
             else               hipLaunchKernelGGL(fa_project_kernel<16>, grid, block, 0, s, G);
+            if (prune) {                                                            // the same contraction on the stacked bases: [T x m] . [m x nfa 16]
+                G.n = MET2_GCV_LR_RANK; G.Dtfa = p->dQt; G.H = p->dH + (size_t)pass * Mh0;
+                if (ks <= 8)       hipLaunchKernelGGL(fa_project_kernel<8>, grid, block, 0, s, G);
+                else if (ks <= 12) hipLaunchKernelGGL(fa_project_kernel<12>, grid, block, 0, s, G);
+                else               hipLaunchKernelGGL(fa_project_kernel<16>, grid, block, 0, s, G);
+                A.Hq = G.H;
+            }
             HIPCHK(hipGetLastError());
             A.H = p->dH;
         }

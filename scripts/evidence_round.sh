@@ -26,11 +26,14 @@ if [ $STAGE = all ] || [ $STAGE = pmc3 ]; then
   pmc gcv_s1_131k -- --config 4 --dims 64,64,32 --nte 32 --nt2 60 --fa single
   pmc bayes_s2_32k -- --config 3 --dims 32,32,32 --nte 48 --nt2 120
   pmc x2_s2_32k -- --config 1 --dims 32,32,32 --nte 48 --nt2 120
+  pmc tv_128x128x64x32 --kernel tv_iter_kernel --sha-files met2_tv.hip -- --workload tv
 fi
 if [ $STAGE = all ] || [ $STAGE = bench ]; then
   bash scripts/bench_configs.sh $TAG
   bash scripts/bench_other_methods.sh $TAG
   python3 scripts/dev_driver_probe.py > gpurun_out/${TAG}_driver_probe.jsonl 2> gpurun_out/${TAG}_driver_probe.err
+  python3 bench.py --workload tv > gpurun_out/${TAG}_tv_bench.json 2> gpurun_out/${TAG}_tv_bench.err
+  python3 scripts/dev_pipeline_probe.py > gpurun_out/${TAG}_pipeline_timing.jsonl 2> gpurun_out/${TAG}_pipeline_timing.err
 fi
 if [ $STAGE = all ] || [ $STAGE = parity ]; then
   python3 tests/tools/parity_report.py --out gpurun_out/parity_${TAG}.json > gpurun_out/parity_${TAG}.log 2>&1

@@ -341,3 +341,38 @@ def test_tie_guard_sides_with_the_reference_on_the_fail_set(pkg):
     assert (e_hip < 1e-7).sum() >= 8 and (e_hip < 1e-7).sum() >= (e_or < 1e-7).sum() - 1
     assert np.all(np.abs(lam - z["ref_lam"]) <= 1e-5)                 # and every answer lies inside Brent's tolerance interval of the reference's lambda
     plan.close()
+
+
+@gpu
+@pytest.mark.parametrize("nte,nt2", [(32, 60), (48, 120)])
+def test_fa_search_with_lower_bounds_finds_the_same_angles(pkg, nte, nt2):
+    """The brute-force FA search skips a flip angle whose least-squares lower bound (||b||^2 - ||Q_fa^T b||^2 in the plan's low-rank
+    basis) exceeds the best NNLS residual found so far: such an angle cannot be np.argmin's answer.  Same indices as the exhaustive
+    walk (MET2_FA_NOPRUNE=1) on 100 000 voxels, the same proton density to rounding; with all residuals asked for nothing is skipped."""
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    alphas = np.linspace(90.0, 180.0, 91)
+    plan = pkg.Met2Plan(nte, nt2, 91)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, alphas, 3000.0).set_penalty("L2", T2s)
+    assert plan.gcv_form()[0]
+    nvox = 100_000
+    data, fa_true, _ = synth.make_voxels(nvox, nte=nte, seed=31 + nte, fa_values=alphas, snr=(20.0, 300.0), device="cuda")
+    data[:7] = 0.0                                                    # gated-out voxels
+    data[7:14, 1:] = 0.0                                              # a degenerate signal: one echo only
+    fa_p, km_p, _ = plan.fa_bruteforce(data)
+    os.environ["MET2_FA_NOPRUNE"] = "1"
+    try:
+        fa_x, km_x, _ = plan.fa_bruteforce(data)
+    finally:
+        os.environ.pop("MET2_FA_NOPRUNE", None)
+    assert torch.equal(fa_p, fa_x), int((fa_p != fa_x).sum())
+    rk = (km_p - km_x).abs() / km_x.abs().clamp(min=1e-300)
+    rel_km = rk.max().item()
+    print("MEASURED fa prune %dx%d: indices identical on %d voxels, max relative |km - km_exhaustive| %.2e (voxel %d), p99.9 %.2e"
+          % (nte, nt2, nvox, rel_km, int(rk.argmax()), torch.quantile(rk[14:], 0.999).item()))
+    assert rel_km < 1e-4 and torch.quantile(rk[14:], 0.999).item() < 1e-7                                              # (a plain-NNLS spectrum is only determined to ~cond(D_P) eps; its residual, which picks the angle, is exact)
+    fa_r, _, resid = plan.fa_bruteforce(data[:5000], want_resid=True)     # every residual is wanted: the exhaustive walk
+    assert torch.equal(fa_r, fa_x[:5000]) and (resid[14:] > 0).all()
+    assert torch.equal(resid.argmin(dim=1)[14:].double(), fa_r[14:])
+    plan.close()
