@@ -6,7 +6,9 @@ ejcanalesr/multicomponent-T2-toolbox).  Package layout:
   intravoxel_algorithms.py  nnls, nnls_tik, nnls_x2, nnls_lcurve_wrapper, nnls_gcv, BayesReg_nnls
   epg.py                    create_Dic_3D, create_met2_design_matrix_epg
   flip_angle_algorithms.py  compute_optimal_FA, fitting_slice_FA_brute_force
-  motor.py                  create_Laplacian_matrix, fitting_slice_T2, recon_met2_arrays (voxel loop)
+  motor.py                  create_Laplacian_matrix, fitting_slice_T2, recon_met2_arrays (voxel loop), nesma_filter, gaussian_smooth, ROI mode
+  tv.py                     tv_denoise_volume / tv_chambolle: denoise='TV' of the driver through met2_tv_chambolle (csrc/met2_tv.hip)
+  nifti.py                  NIfTI-1 reader / writer for the driver's on-disk contract
   dist.py                   one-process-per-GPU voxel sharding + the single gather of output maps
   synth.py                  seeded synthetic volumes (the reference's Monte-Carlo recipe)
 

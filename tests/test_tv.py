@@ -122,10 +122,12 @@ def _check(vol, got, sig, its, weight=None, tol=1e-12):
 
 
 @gpu
-@pytest.mark.parametrize("shape,nt", [((20, 18, 24), 3), ((9, 37, 70), 2), ((35, 16, 64), 4), ((17, 33, 130), 1), ((3, 2, 5), 2)])
+@pytest.mark.parametrize("shape,nt", [((20, 18, 24), 3), ((9, 37, 70), 2), ((35, 16, 64), 4), ((17, 33, 130), 1), ((3, 2, 5), 2), ((14, 11, 1), 2), ((1, 12, 9), 1),
+                                      ((16, 1, 20), 2)])
 def test_hip_tv_matches_the_numpy_restatement(shape, nt):
     """C-ordered volumes: one tile, tiles with halo rows along axis 1 (33, 37 > 15), halo lanes along axis 2 (70, 130 > 63),
-    several segments along axis 0 (35 > 16), a volume smaller than any tile."""
+    several segments along axis 0 (35 > 16), a volume smaller than any tile, volumes with a singleton axis (a 2-D slice kept as a 3-D array:
+    scikit-image still runs its three-axis iteration with tau = 1/6 on it)."""
     tv = importlib.import_module(PKG + ".tv")
     vol = _phantom(shape, nt, seed=sum(shape) + nt)
     got, sig, its = tv.tv_denoise_volume(vol, return_info=True)
