@@ -391,8 +391,8 @@ __device__ __forceinline__ double fminbound_dev(F &&fn, G &&on_best, double x1, 
 }
 
 // X2: Brent's near-ties are decided on refined objective values (fminbound_tie_dev).  Measured on one MI355X (profiles/r04_tie_guard.txt):
-// the 13 voxels of tests/golden/golden_x2_failset.npz (HIP and oracle disagree) -- HIP equals the REFERENCE in 9 instead of 4, as the
-// oracle does; the 65 536-voxel reference fixture -- 2 voxels beyond 1e-5 instead of 3 (the oracle: 2); 3.4 % of the voxels take a
+// the 13 voxels of tests/golden/golden_x2_failset.npz (HIP and the CPU checker disagree) -- HIP equals the REFERENCE in 9 instead of 4, as the
+// checker does; the 65 536-voxel reference fixture -- 2 voxels beyond 1e-5 instead of 3 (the checker: 2); 3.4 % of the voxels take a
 // refined evaluation; configs[1] 149.2 -> 150.1 ms (+0.4 % for the code being there, the rest for the refinements).
 // 0: scipy's search verbatim (fminbound_dev); 2: also flag the voxels that refined and why (status bits 64, 256..4096: debugging).
 #ifndef MET2_TIE_GUARD
