@@ -1198,7 +1198,8 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
         u64 cand[VPW][2];                      // flip angles whose bound does not exceed the best residual so far (wave-uniform masks; all ones: no pruning)
         // the masks are formed again whenever the best residual improves: lane f compares its angle's parked bound
         auto candidates = [&](int vv) {
-            const double thr = fma(best_r[vv] * best_r[vv], 1.0 + 1e-6, slack[vv]);
+            const double tb = fma(best_r[vv], 1.0 + 1e-6, slack[vv]);     // sqrt(lb) > best (1 + 1e-6) + 1e-7 ||b||, compared as squares
+            const double thr = tb * tb;
             const double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
@@ -1223,7 +1224,11 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
                     l2[sl] = (f < A.nfa) ? bb2 - cs : INFINITY;
                     if (f < A.nfa) q[(size_t)f * MET2_GCV_LR_RANK] = l2[sl];
                 }
-                slack[vv] = 1e-13 * bb2;                                  // rounding of the difference above
+                // What the bound may be off by: the basis leaves E = (I - Q Q^T) D, ||E|| <= 1e-9 of the largest column, outside, and the residual
+                // of ANY x is at least ||b_perp|| - ||E x||; with ||x||_1 <= a few ||b|| per unit column norm (x >= 0 and a dictionary of decaying
+                // signals: the first echo alone bounds x) that is < 1e-8 ||b||.  1e-7 ||b|| covers it sixteen times over and the rounding of
+                // the difference above (1e-16 ||b||^2, i.e. 1e-8 ||b|| at worst) as well; on noisy data it prunes nothing less.
+                slack[vv] = 1e-7 * sqrt(bb2);
                 const double mn = wave_min(fmin(l2[0], l2[1]));
                 const u64 m0 = ballot(l2[0] == mn), m1 = ballot(l2[1] == mn);
                 fa0[vv] = m0 ? first_lane(m0) : 64 + first_lane(m1);
