@@ -323,7 +323,18 @@ __device__ __forceinline__ double tv_minus_div(const TvPlane &q, double p0m, boo
 #ifndef MET2_TV_WPE
 #define MET2_TV_WPE 1          // minimum waves per SIMD the kernel is compiled for: 1 = 72 VGPRs, 7 waves; 8 = 64 VGPRs with 6 spilled: 0.484 instead of 0.382 ms per iteration
 #endif
-template <int OY, bool REV>
+__device__ __forceinline__ double bcast_lane(double v, int l)        // lane l's value in every lane (l a compile-time constant at the call sites)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// EDGE: the contiguous axis is longer than a wave (n2 > 64).  Tiles along it are 64 lanes wide WITHOUT overlap; what lane 63 needs from the
+// next tile -- `out` at column z0 + 64 of its own row -- is formed in the wave itself: per plane, lanes 0..4 fetch that column's p0, p1, p2,
+// f and p1 of the row below with ONE load, the values are broadcast and every lane forms the (wave-uniform) out.  Eight registers instead
+// of a 64th lane that owns nothing: with overlapping 63-lane tiles a volume of 128 along this axis took three tiles per row, the last one
+// with two live lanes, and its loads straddled the 512-byte segments (3.25 instead of 5.2 TB/s; a Fortran-ordered volume has nx here).
+template <int OY, bool REV, bool EDGE>
 __global__ __launch_bounds__(64 * OY, MET2_TV_WPE) void tv_iter_kernel(TvIterArgs A)
 {
 #pragma clang fp contract(off)
@@ -342,6 +353,8 @@ __global__ __launch_bounds__(64 * OY, MET2_TV_WPE) void tv_iter_kernel(TvIterArg
     const bool own = in && wy < A.step1 && lane < A.step2;
     const bool h1 = y >= 1, h2 = z >= 1;                             // a lower neighbour exists along axis 1 / 2
     const bool u1 = in && y + 1 < n1 && wy + 1 < OY, u2 = in && z + 1 < n2 && lane + 1 < 64;   // an upper neighbour, held by this workgroup
+    const bool etile = EDGE && (z - lane + 64 < n2);                 // the tile has a neighbour along axis 2 (wave-uniform)
+    const bool e2 = etile && in && lane == 63;                       // ... whose first column is this lane's upper neighbour
     const double weight = A.state[t].weight;
     const double tau = 1.0 / 6.0;
     const double r = tau / weight;
@@ -368,6 +381,25 @@ __global__ __launch_bounds__(64 * OY, MET2_TV_WPE) void tv_iter_kernel(TvIterArg
         out_c = cur.f + d_c;
         if (xs + 1 < n0) nxt = load(at + s0);
     }
+    // the neighbour tile's first column (EDGE): lane k < 6 fetches item k of {p0, p1, p2, f, p1 of the row below, p0 of the plane before}
+    const double *hbase = (lane == 0 || lane == 5) ? q0 : ((lane == 1 || lane == 4) ? q1 : (lane == 2 ? q2 : f));
+    const bool hrow = etile && y < n1;
+    const int64_t hat = ((int64_t)xs * n1 + (hrow ? y : 0)) * n2 + (hrow ? z - lane + 64 : 0) - (lane == 4 ? n2 : 0) - (lane == 5 ? s0 : 0);
+    const bool hact = hrow && (lane < 4 || (lane == 4 && h1) || (lane == 5 && xs >= 1));
+    auto hload = [&](int k) { return (hact && (lane < 5 || k == 0)) ? hbase[hat + (int64_t)k * s0] : 0.0; };
+    auto hout = [&](double hv, double p0prev, bool hasprev, double p2own) {      // out at the neighbour column from one plane's six numbers
+        TvPlane q;
+        q.p0 = bcast_lane(hv, 0); q.p1 = bcast_lane(hv, 1); q.p2 = bcast_lane(hv, 2); q.f = bcast_lane(hv, 3); q.p1m = bcast_lane(hv, 4);
+        q.p2m = p2own;                                               // its lower neighbour along axis 2 is this wave's last column
+        return q.f + tv_minus_div<REV>(q, p0prev, hasprev, h1, true);
+    };
+    double hnxt = 0.0, hnn = 0.0, hp0 = 0.0, oh_c = 0.0;             // next plane's six numbers, the plane after; p0 of the current plane; out of the current plane
+    if (EDGE && etile) {
+        const double h0v = hload(0);
+        oh_c = hout(h0v, bcast_lane(h0v, 5), xs >= 1, bcast_lane(cur.p2, 63));
+        hp0 = bcast_lane(h0v, 0);
+        if (xs + 1 < n0) hnxt = hload(1);
+    }
     outp[0][wy][lane] = out_c;
     __syncthreads();
     double acc_d = 0.0, acc_n = 0.0;
@@ -376,11 +408,14 @@ __global__ __launch_bounds__(64 * OY, MET2_TV_WPE) void tv_iter_kernel(TvIterArg
         const int b = (x - xs) & 1;
         const bool more = x + 1 < n0;
         if (in && x + 2 < n0 && x + 1 < xe) nn = load(i + 2 * s0);   // two planes ahead: in flight under this plane's arithmetic
+        if (EDGE && etile && x + 2 < n0 && x + 1 < xe) hnn = hload(x + 2 - xs);
         double out_n = 0.0, d_n = 0.0;
         if (more) { d_n = tv_minus_div<REV>(nxt, cur.p0, true, h1, h2); out_n = nxt.f + d_n; }
+        double oh_n = 0.0;
+        if (EDGE && etile && more) oh_n = hout(hnxt, hp0, true, bcast_lane(nxt.p2, 63));
         const double g0 = more ? out_n - out_c : 0.0;
         const double g1 = u1 ? outp[b][wy + 1][lane] - out_c : 0.0;
-        const double g2 = u2 ? outp[b][wy][lane + 1] - out_c : 0.0;
+        const double g2 = (EDGE && e2) ? oh_c - out_c : (u2 ? outp[b][wy][lane + 1] - out_c : 0.0);
         outp[b ^ 1][wy][lane] = out_n;
         if (own) {
             const double nrm = REV ? sqrt((g2 * g2 + g1 * g1) + g0 * g0) : sqrt((g0 * g0 + g1 * g1) + g2 * g2);
@@ -398,6 +433,7 @@ __global__ __launch_bounds__(64 * OY, MET2_TV_WPE) void tv_iter_kernel(TvIterArg
 #endif
         }
         cur = nxt; nxt = nn; out_c = out_n; d_c = d_n;
+        if (EDGE) { hp0 = bcast_lane(hnxt, 0); hnxt = hnn; oh_c = oh_n; }
         __syncthreads();
     }
     acc_d = wave_sum_d(acc_d); acc_n = wave_sum_d(acc_n);
@@ -509,7 +545,7 @@ void tv_layout(int n0, int n1, int n2, int nt, TvLayout &L)
     L.oy = tv_env("MET2_TV_OY", 8);                                  // rows of a tile = waves of a workgroup; measured 4 / 8 / 16: 0.387 / 0.381 / 0.428 ms per iteration
     if (L.oy != 4 && L.oy != 8 && L.oy != 16) L.oy = 8;
     L.step1 = n1 <= L.oy ? L.oy : L.oy - 1;                          // a tile that spans the axis needs no halo row
-    L.step2 = n2 <= 64 ? 64 : 63;
+    L.step2 = 64;                                                    // no overlap along the contiguous axis (tv_iter_kernel: EDGE)
     L.nt1 = (n1 + L.step1 - 1) / L.step1; L.nt2 = (n2 + L.step2 - 1) / L.step2;
     L.xlen = std::max(1, std::min(n0, tv_env("MET2_TV_XLEN", 16)));
     L.nseg = (n0 + L.xlen - 1) / L.xlen;
@@ -538,9 +574,17 @@ template <bool REV>
 void launch_iter(const TvIterArgs &A, int oy, int nt, hipStream_t s)
 {
     const dim3 grid((unsigned)(((A.ntiles + 7) / 8) * 8), (unsigned)nt);
-    if (oy == 4)       hipLaunchKernelGGL((tv_iter_kernel<4, REV>), grid, dim3(256), 0, s, A);
-    else if (oy == 8)  hipLaunchKernelGGL((tv_iter_kernel<8, REV>), grid, dim3(512), 0, s, A);
-    else               hipLaunchKernelGGL((tv_iter_kernel<16, REV>), grid, dim3(1024), 0, s, A);
+    const bool edge = A.n2 > 64;
+    if (oy == 4) {
+        if (edge) hipLaunchKernelGGL((tv_iter_kernel<4, REV, true>), grid, dim3(256), 0, s, A);
+        else      hipLaunchKernelGGL((tv_iter_kernel<4, REV, false>), grid, dim3(256), 0, s, A);
+    } else if (oy == 8) {
+        if (edge) hipLaunchKernelGGL((tv_iter_kernel<8, REV, true>), grid, dim3(512), 0, s, A);
+        else      hipLaunchKernelGGL((tv_iter_kernel<8, REV, false>), grid, dim3(512), 0, s, A);
+    } else {
+        if (edge) hipLaunchKernelGGL((tv_iter_kernel<16, REV, true>), grid, dim3(1024), 0, s, A);
+        else      hipLaunchKernelGGL((tv_iter_kernel<16, REV, false>), grid, dim3(1024), 0, s, A);
+    }
 }
 
 }  // namespace
