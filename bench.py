@@ -69,7 +69,7 @@ def host_cores():
     return int(os.environ.get("MET2_CPU_THREADS", n))
 
 
-def source_sha(files=("met2_hip.hip", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp")):
+def source_sha(files=("met2_hip.hip", "fit_kernel.hpp", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp")):
     """Digest of the kernel sources: counter files under profiles/ are only quoted while they describe this build."""
     h = hashlib.sha256()
     for f in files:

@@ -1,0 +1,6 @@
+// met2_fit_x2_nb1.hip -- explicit instantiations of the fit kernel for one family of methods (fit_kernel.hpp); empty unless -DMET2_SPLIT_TU.
+#ifdef MET2_SPLIT_TU
+#include "fit_kernel.hpp"
+template int launch_fit_nb<2, 1, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<12, 1, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
+#endif

@@ -4,7 +4,8 @@
 Registers, spills and occupancy from hipcc -Rpass-analysis=kernel-resource-usage; v_mfma_f64_16x16x4 counts from the -S output."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRCS = [os.path.join(ROOT, "multicomponent-t2-toolbox_amd", "csrc", f) for f in ("met2_hip.hip", "met2_tv.hip")]
+SRCS = [os.path.join(ROOT, "multicomponent-t2-toolbox_amd", "csrc", f) for f in ("met2_hip.hip", "met2_fit_x2_nb1.hip", "met2_fit_x2_nb2.hip", "met2_fit_x2_second.hip", "met2_fit_nnls_lcurve.hip",
+                                                                                  "met2_fit_gcv.hip", "met2_fit_bayes.hip", "met2_tv.hip")]
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
@@ -17,7 +18,7 @@ def main():
     blocks, s = [], ""
     for i, src in enumerate(SRCS):
         asm = os.path.join(tmp, "k%d.s" % i)
-        p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-disable-machine-licm", "-S", "--cuda-device-only",
+        p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-disable-machine-licm", "-DMET2_SPLIT_TU", "-S", "--cuda-device-only",
                             "-Rpass-analysis=kernel-resource-usage", "-o", asm, src], capture_output=True, text=True)
         blocks += re.split(r"remark: Function Name: ", p.stderr)[1:]
         s += open(asm).read()
