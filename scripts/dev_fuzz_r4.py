@@ -1,0 +1,38 @@
+import importlib, sys, os
+import numpy as np, torch
+sys.path.insert(0, ".")
+PKG="multicomponent-t2-toolbox_amd"
+pkg=importlib.import_module(PKG); tv=importlib.import_module(PKG+".tv"); synth=importlib.import_module(PKG+".synth")
+from oracle import tv_oracle, oracle
+oracle.build()
+rng=np.random.default_rng(1)
+# TV: random shapes, both layouts
+bad=0
+for trial in range(24):
+    shape=tuple(int(v) for v in rng.integers(1, [40, 40, 150]))
+    nt=int(rng.integers(1,5))
+    vol=np.abs(50+10*rng.standard_normal(shape+(nt,)) + 30*(np.arange(shape[0])[:,None,None,None]>shape[0]//2))
+    for fortran in (False, True):
+        t=torch.as_tensor(np.asfortranarray(vol) if fortran else vol, device="cuda")
+        got,sig,its=tv.tv_chambolle(t, return_info=True)
+        got=got.cpu().numpy()
+        for e in range(nt):
+            v=np.ascontiguousarray(vol[...,e]); s=tv_oracle.estimate_sigma(v); w=2*s
+            if not (w>0): ref,n=v,0
+            else: ref,n=tv_oracle.denoise_tv_chambolle(v,w,return_iters=True)
+            err=np.max(np.abs(got[...,e]-ref))/max(np.max(np.abs(ref)),1e-300)
+            if err>1e-12 or n!=its[e] or abs(sig[e]-s)>1e-13*max(s,1e-300):
+                bad+=1; print("TV MISMATCH", shape, nt, fortran, e, err, n, its[e], sig[e], s)
+print("tv fuzz done, mismatches:", bad)
+# FA prune vs exhaustive for several nfa / shapes
+for nte,nt2,nfa in ((32,60,8),(32,60,128),(20,33,40),(48,120,91),(63,128,17)):
+    T2s=synth.t2_grid(nt2); al=np.linspace(100,180,nfa)
+    plan=pkg.Met2Plan(nte,nt2,nfa); plan.build_dictionary_epg(T2s,1000*np.ones(nt2),10.0,al,3000.0).set_penalty("L2",T2s)
+    data,_,_=synth.make_voxels(20000,nte=nte,seed=nfa,fa_values=al,snr=(10,500),device="cuda")
+    a,_,_=plan.fa_bruteforce(data)
+    os.environ["MET2_FA_NOPRUNE"]="1"; b,_,_=plan.fa_bruteforce(data); os.environ.pop("MET2_FA_NOPRUNE")
+    print("FA", nte,nt2,nfa, "gcv_form", plan.gcv_form(), "mismatches", int((a!=b).sum()))
+    # GCV fit runs
+    out=plan.fit("GCV", data[:2000], fa_index=a[:2000], want_lambda=True)
+    st=out["status"].cpu().numpy(); print("   GCV status ok", bool((st==1).all()), "lam range", float(out["lam"].min()), float(out["lam"].max()))
+    plan.close()

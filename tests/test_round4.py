@@ -376,3 +376,43 @@ def test_fa_search_with_lower_bounds_finds_the_same_angles(pkg, nte, nt2):
     assert torch.equal(fa_r, fa_x[:5000]) and (resid[14:] > 0).all()
     assert torch.equal(resid.argmin(dim=1)[14:].double(), fa_r[14:])
     plan.close()
+
+
+@gpu
+def test_random_shapes_through_the_round4_paths(pkg):
+    """Random small shapes through what round 4 added: the TV kernels in both memory layouts against the numpy restatement (tiles that end inside
+    a wave, axes shorter than a tile, more than one lane tile), and the lower-bound FA search against the exhaustive walk for plans of 8 to 128
+    flip angles, followed by a GCV fit on the low-rank trace."""
+    import torch
+    from oracle import tv_oracle
+    tv = importlib.import_module(PKG + ".tv")
+    synth = importlib.import_module(PKG + ".synth")
+    rng = np.random.default_rng(1)
+    for trial in range(10):
+        shape = tuple(int(v) for v in rng.integers(1, [30, 30, 150]))
+        nt = int(rng.integers(1, 4))
+        vol = np.abs(50 + 10 * rng.standard_normal(shape + (nt,)) + 30 * (np.arange(shape[0])[:, None, None, None] > shape[0] // 2))
+        for fortran in (False, True):
+            t = torch.as_tensor(np.asfortranarray(vol) if fortran else vol, device="cuda")
+            got, sig, its = tv.tv_chambolle(t, return_info=True)
+            got = got.cpu().numpy()
+            for e in range(nt):
+                v = np.ascontiguousarray(vol[..., e]); s = tv_oracle.estimate_sigma(v)
+                ref, n = (tv_oracle.denoise_tv_chambolle(v, 2 * s, return_iters=True) if 2 * s > 0 else (v, 0))
+                assert n == its[e] and abs(sig[e] - s) <= 1e-13 * max(s, 1e-300), (shape, nt, fortran, e, n, its[e])
+                assert np.max(np.abs(got[..., e] - ref)) <= 1e-12 * np.max(np.abs(ref)), (shape, nt, fortran, e)
+    for nte, nt2, nfa in ((32, 60, 8), (20, 33, 40), (63, 128, 17), (32, 60, 128)):
+        T2s = synth.t2_grid(nt2); al = np.linspace(100.0, 180.0, nfa)
+        plan = pkg.Met2Plan(nte, nt2, nfa)
+        plan.build_dictionary_epg(T2s, 1000.0 * np.ones(nt2), 10.0, al, 3000.0).set_penalty("L2", T2s)
+        data, _, _ = synth.make_voxels(6000, nte=nte, seed=nfa, fa_values=al, snr=(10.0, 500.0), device="cuda")
+        a, _, _ = plan.fa_bruteforce(data)
+        os.environ["MET2_FA_NOPRUNE"] = "1"
+        try:
+            b, _, _ = plan.fa_bruteforce(data)
+        finally:
+            os.environ.pop("MET2_FA_NOPRUNE", None)
+        assert torch.equal(a, b), (nte, nt2, nfa, int((a != b).sum()))
+        out = plan.fit("GCV", data[:1500], fa_index=a[:1500], want_lambda=True)
+        assert (out["status"] == 1).all() and (out["lam"] >= 1e-8).all() and (out["lam"] <= 10.0).all()
+        plan.close()
