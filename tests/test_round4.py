@@ -416,3 +416,27 @@ def test_random_shapes_through_the_round4_paths(pkg):
         out = plan.fit("GCV", data[:1500], fa_index=a[:1500], want_lambda=True)
         assert (out["status"] == 1).all() and (out["lam"] >= 1e-8).all() and (out["lam"] <= 10.0).all()
         plan.close()
+
+
+@gpu
+def test_bench_tv_workload_line():
+    """`bench.py --workload tv`: one JSON line with the contract's keys, the HBM roofline block of the stencil kernel (56 algorithmic bytes per
+    (voxel, echo) and iteration over the HIP-event time of the iteration launches), a numpy CPU baseline and the parity block against the
+    restatement (which says that it is unpinned)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tv", "--dims", "40,36,32", "--nte", "6", "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline"):
+        assert k in line, k
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bytes_per_voxel_echo_iteration"] == 56 and r["active_echo_iterations"] == sum(line["config"]["iterations_per_echo"])
+    assert line["unit"] == "voxels/s" and line["dtype"] == "f64" and line["vs_baseline"] is None and line["n_gpus"] == 1
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 0
+    assert "UNPINNED" in line["parity"]["against"] and line["parity"]["max_rel"] <= 1e-12
+    assert line["parity"]["iterations_hip_oracle"][0] == line["parity"]["iterations_hip_oracle"][1]
