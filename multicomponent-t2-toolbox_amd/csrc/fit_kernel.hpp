@@ -210,7 +210,7 @@ __device__ __forceinline__ double fminbound_tie_dev(F &&fn, G &&on_best, double 
                 const bool c1 = fabs(fabs(p) - t1) < KAP * (fabs(p) + t1), c2 = fabs(p - t2) < KAP * (fabs(p) + fabs(t2)), c3 = fabs(t3 - p) < KAP * (fabs(p) + fabs(t3));
                 const bool c4 = (fulc != xf && fabs(fx - ffulc) < TAU) || (nfc != xf && fabs(fx - fnfc) < TAU);      // (a retained point that IS xf: no parabola, not a tie)
                 const bool close = c1 || c2 || c3 || c4;
-                if (!close) break;
+                if (__builtin_expect(!close, 1)) break;
                 nref |= (c1 ? 1 << 8 : 0) | (c2 ? 1 << 9 : 0) | (c3 ? 1 << 10 : 0) | (c4 ? 1 << 11 : 0);
                 refine3();
             }
@@ -236,7 +236,7 @@ __device__ __forceinline__ double fminbound_tie_dev(F &&fn, G &&on_best, double 
         fu = fn(x, false);
         bool ru = false;
         num++;
-        if (fabs(fu - fx) < TAU || fabs(fu - fnfc) < TAU || fabs(fu - ffulc) < TAU) {
+        if (__builtin_expect(fabs(fu - fx) < TAU || fabs(fu - fnfc) < TAU || fabs(fu - ffulc) < TAU, 0)) {
             nref |= 1 << 12;
             refine3();                                                // (leaves the solver at xf)
             fu = fn(x, true); ru = true; ++nref;

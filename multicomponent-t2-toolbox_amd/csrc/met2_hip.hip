@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256) void fa_project_kernel(FaGemmArgs A)
     }
 }
 
-template <int VPW, int NB, int WAVES>
+// PRUNE: the walk skips flip angles by their lower bounds (A.Hq); a separate instantiation keeps the exhaustive walk (all residuals wanted: the
+// spline path; few flip angles) free of the masks and the extra round
+template <int VPW, int NB, int WAVES, bool PRUNE>
 __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #pragma unroll
         for (int vv = 0; vv < VPW; ++vv) {
             slack[vv] = 0.0; fa0[vv] = -1; cand[vv][0] = cand[vv][1] = ~0ull;
-            if (A.Hq && act[vv]) {
+            if (PRUNE && A.Hq && act[vv]) {
                 const double bb2 = wave_sum(b[vv] * b[vv]);
                 double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
                 double l2[2];
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
                 fa0[vv] = m0 ? first_lane(m0) : 64 + first_lane(m1);
             }
         }
-        for (int i = A.Hq ? -1 : 0; i < A.nfa; ++i) {
+        for (int i = (PRUNE && A.Hq) ? -1 : 0; i < A.nfa; ++i) {
 #ifdef MET2_CYCSTATS
             const unsigned long long cv0 = __builtin_readcyclecounter();
 #endif
@@ -494,9 +496,9 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             }
 #pragma unroll
             for (int vv = 0; vv < VPW; ++vv) {
-                const int fa = (i < 0) ? fa0[vv] : i;
-                if (!act[vv] || fa < 0 || (i >= 0 && fa == fa0[vv])) continue;
-                if (!((cand[vv][fa >> 6] >> (fa & 63)) & 1ull)) continue;            // its lower bound exceeds the best residual: cannot be the argmin
+                const int fa = (PRUNE && i < 0) ? fa0[vv] : i;
+                if (!act[vv] || (PRUNE && (fa < 0 || (i >= 0 && fa == fa0[vv])))) continue;
+                if (PRUNE && !((cand[vv][fa >> 6] >> (fa & 63)) & 1ull)) continue;   // its lower bound exceeds the best residual: cannot be the argmin
                 if (A.H) {                     // h of this flip angle from the batched MFMA contraction: one contiguous row per voxel
                     const double *Bf = A.Bfa + (size_t)fa * n * n;
                     S.B = Bf; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #pragma unroll
                     for (int bb = 0; bb < NB; ++bb) t += (lane + 64 * bb < n) ? st[vv].x[bb] : 0.0;
                     best_km[vv] = wave_sum(t);
-                    if (A.Hq) candidates(vv);
+                    if (PRUNE && A.Hq) candidates(vv);
                 }
             }
 #ifdef MET2_CYCSTATS
@@ -1968,8 +1970,13 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     HIPCHK(hipEventRecord(p->ev0, s));
 #define MET2_FA_LAUNCH(VPW, NB, WAVES)                                                                                   \
     do {                                                                                                                \
-        HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
-        hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES>), dim3(g.grid), dim3(g.block), g.lds, s, A);                       \
+        if (A.Hq) {                                                                                                     \
+            HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
+            hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES, true>), dim3(g.grid), dim3(g.block), g.lds, s, A);              \
+        } else {                                                                                                        \
+            HIPCHK(hipFuncSetAttribute((const void *)fa_kernel<VPW, NB, WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds)); \
+            hipLaunchKernelGGL((fa_kernel<VPW, NB, WAVES, false>), dim3(g.grid), dim3(g.block), g.lds, s, A);             \
+        }                                                                                                               \
     } while (0)
     for (int64_t v0 = 0; v0 < nvox; v0 += pass) {
         A.v0 = v0; A.v_end = std::min<int64_t>(nvox, v0 + pass); A.H = nullptr; A.Hq = nullptr;
