@@ -235,7 +235,8 @@ int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, int32_t n_te,
  * has sigma = 0; scikit-image would return nan for it).
  * eps, max_num_iter: the reference passes 2e-4 and 200.  poll_every: 0 = every iteration of max_num_iter is enqueued and the call
  * returns without waiting (launches for echoes that have converged return at once); k > 0 = the host looks at the device's flags
- * every k iterations and stops enqueueing when every echo has converged (the call then blocks until that point).
+ * every k iterations -- one batch of k behind the stream, so that the stream never waits for the host -- and stops enqueueing when
+ * every echo has converged (the call then blocks until about that point; up to 2k launches that return at once are enqueued past it).
  * DEVICE out, may be NULL: sigma [n_te] the estimated noise level per echo (nan if the echo holds a nan or inf -- the reference's
  * finite check would raise), iters [n_te] int32 Chambolle iterations executed per echo.
  * work: DEVICE scratch of met2_tv_work_bytes() bytes (7 working copies of the volume), or NULL: allocated and freed inside, which

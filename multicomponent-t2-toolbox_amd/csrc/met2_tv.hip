@@ -564,7 +564,9 @@ void tv_layout(int n0, int n1, int n2, int nt, TvLayout &L)
 
 // HIP events around the iteration launches of the calling thread's most recent met2_tv_chambolle (met2_tv_last_timing)
 struct TvTiming {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, pe[2] = {nullptr, nullptr};   // pe: the two poll copies in flight
+    TvState *hpin = nullptr;                                         // pinned: [2][hpin_cap] copies of the echoes' states
+    int hpin_cap = 0;
     int launches = 0, device = -1;
     bool valid = false;
 };
@@ -655,13 +657,22 @@ extern "C" int met2_tv_chambolle(int32_t device, int32_t nx, int32_t ny, int32_t
     I.ntiles = L.ntiles; I.vol = L.vol; I.F = Fsrc; I.partial = partial; I.state = state;
     TvReduceArgs R;
     R.ntiles = L.ntiles; R.max_iter = max_num_iter; R.eps = eps; R.size = (double)L.vol; R.partial = partial; R.state = state;
-    std::vector<TvState> hstate;
     TvTiming &T = g_tv_timing;
     T.valid = false;
     if (!T.e0 || T.device != device) {
-        if (T.e0) { (void)hipEventDestroy(T.e0); (void)hipEventDestroy(T.e1); T.e0 = T.e1 = nullptr; }
+        if (T.e0) {
+            (void)hipEventDestroy(T.e0); (void)hipEventDestroy(T.e1); (void)hipEventDestroy(T.pe[0]); (void)hipEventDestroy(T.pe[1]);
+            T.e0 = T.e1 = T.pe[0] = T.pe[1] = nullptr;
+        }
+        if (T.hpin) { (void)hipHostFree(T.hpin); T.hpin = nullptr; T.hpin_cap = 0; }
         HIPCHK(hipEventCreate(&T.e0)); HIPCHK(hipEventCreate(&T.e1));
+        HIPCHK(hipEventCreateWithFlags(&T.pe[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&T.pe[1], hipEventDisableTiming));
         T.device = device;
+    }
+    if (poll_every > 0 && T.hpin_cap < n_te) {
+        if (T.hpin) { (void)hipHostFree(T.hpin); T.hpin = nullptr; T.hpin_cap = 0; }
+        HIPCHK(hipHostMalloc((void **)&T.hpin, sizeof(TvState) * 2 * (size_t)n_te, hipHostMallocDefault));
+        T.hpin_cap = n_te;
     }
     HIPCHK(hipEventRecord(T.e0, s));
     T.launches = 0;
@@ -671,13 +682,20 @@ extern "C" int met2_tv_chambolle(int32_t device, int32_t nx, int32_t ny, int32_t
         R.iter = it;
         hipLaunchKernelGGL(tv_reduce_kernel, dim3((unsigned)n_te), dim3(256), 0, s, R);
         T.launches = it + 1;
+        // The host stops launching once every echo is done.  It looks at the flags ONE batch late: the copy of poll k is read after batch
+        // k + 1 has been enqueued, so the stream never runs dry while the host waits (a blocking read per poll left a 40 us bubble each
+        // time; the price is up to poll_every more launches that return at once).
         if (poll_every > 0 && (it + 1) % poll_every == 0 && it + 1 < max_num_iter) {
-            hstate.resize(n_te);
-            HIPCHK(hipMemcpyAsync(hstate.data(), state, sizeof(TvState) * n_te, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            bool all = true;
-            for (int t = 0; t < n_te; ++t) all = all && hstate[t].done;
-            if (all) break;
+            const int k = (it + 1) / poll_every - 1;
+            HIPCHK(hipMemcpyAsync(T.hpin + (size_t)(k & 1) * T.hpin_cap, state, sizeof(TvState) * n_te, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipEventRecord(T.pe[k & 1], s));
+            if (k >= 1) {
+                HIPCHK(hipEventSynchronize(T.pe[(k - 1) & 1]));
+                const TvState *h = T.hpin + (size_t)((k - 1) & 1) * T.hpin_cap;
+                bool all = true;
+                for (int t = 0; t < n_te; ++t) all = all && h[t].done;
+                if (all) break;
+            }
         }
     }
     HIPCHK(hipEventRecord(T.e1, s));

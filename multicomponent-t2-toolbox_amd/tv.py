@@ -23,7 +23,7 @@ def _layout(data):
     return data.contiguous(), 0
 
 
-def tv_chambolle(data, weight=None, weight_factor=2.0, eps=2.0e-4, max_num_iter=200, poll_every=8, device=0, return_info=False):
+def tv_chambolle(data, weight=None, weight_factor=2.0, eps=2.0e-4, max_num_iter=200, poll_every=4, device=0, return_info=False):
     """Every echo volume of data [nx,ny,nz,nt] through denoise_tv_chambolle; `weight` = one weight per echo (array) or None:
     weight_factor x the echo's estimate_sigma.  numpy in -> numpy out, CUDA tensor in -> tensor out (same memory order).
     return_info: also (sigma [nt], iterations [nt]) as numpy arrays."""
