@@ -1273,6 +1273,9 @@ extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
     return MET2_OK;
 }
 
+struct SplineTables { int device = -1; double *d = nullptr; size_t cap = 0; std::vector<double> last; };
+static thread_local SplineTables g_spline_tables;
+
 extern "C" int met2_fa_spline_select_strided(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
                                              int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, int64_t voxel_stride,
                                              int64_t echo_stride, const uint8_t *mask, double *fa_index, double *xmin, void *stream)
@@ -1287,22 +1290,33 @@ extern "C" int met2_fa_spline_select_strided(int32_t device, int64_t nvox, int32
     hipStream_t s = (hipStream_t)stream;
     std::vector<double> W;
     spline_weights_host(n_lr, alpha_lr, W);
-    double *dbuf = nullptr;
     const size_t nd = (size_t)n_lr + (size_t)n_lr * n_lr + (size_t)n_hr;
-    HIPCHK(hipMalloc(&dbuf, sizeof(double) * nd));
     std::vector<double> hb(nd);
     memcpy(hb.data(), alpha_lr, sizeof(double) * n_lr);
     memcpy(hb.data() + n_lr, W.data(), sizeof(double) * n_lr * n_lr);
     memcpy(hb.data() + n_lr + (size_t)n_lr * n_lr, alpha_hr, sizeof(double) * n_hr);
-    HIPCHK(hipMemcpyAsync(dbuf, hb.data(), sizeof(double) * nd, hipMemcpyHostToDevice, s));
+    // The tables (two grids and the spline's weight matrix, a few KB) live in a per-thread device buffer that is written only when they
+    // CHANGE: a driver calls this once per chunk with the same grids, and an allocation + blocking wait + hipFree per call stood in the
+    // way of its pipeline (hipFree waits for the whole device).  Changing them waits for the device first (a kernel of an earlier call may
+    // still read the old ones).
+    SplineTables &T = g_spline_tables;
+    if (T.device != device || T.cap < nd) {
+        if (T.d) { DevGuard old(T.device); HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(T.d)); T.d = nullptr; T.cap = 0; T.last.clear(); }
+        HIPCHK(hipMalloc((void **)&T.d, sizeof(double) * std::max<size_t>(nd, 2048)));
+        T.cap = std::max<size_t>(nd, 2048); T.device = device;
+    }
+    if (T.last != hb) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(T.d, hb.data(), sizeof(double) * nd, hipMemcpyHostToDevice));
+        T.last = hb;
+    }
+    double *dbuf = T.d;
     SplineArgs A;
     A.nlr = n_lr; A.nhr = n_hr; A.nte = n_te;
     A.alpha_lr = dbuf; A.W = dbuf + n_lr; A.alpha_hr = dbuf + n_lr + (size_t)n_lr * n_lr;
     A.resid = resid; A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.mask = mask; A.fa_index = fa_index; A.xmin = xmin; A.nvox = nvox;
     hipLaunchKernelGGL(fa_spline_kernel, dim3((unsigned)((nvox + 127) / 128)), dim3(128), 0, s, A);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(dbuf));
     return MET2_OK;
 }
 

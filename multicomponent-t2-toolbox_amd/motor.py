@@ -108,7 +108,7 @@ def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
 
 
 def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=262144, want_lambda=False, out=None,
-                      echo_major=False, mask_values=None):
+                      echo_major=False, mask_values=None, device_data=None, device_fa_data=None):
     """Driver steps 2-4 (motor:349-373, 427-472) for a voxel list that lives in HOST memory, as the reference's driver holds it
     (motor:167-182): chunks of `chunk` voxels go H2D on one stream, through [FA estimation and] the fit on a second, and the
     outputs D2H on a third, double-buffered, so that the copies of chunks c+1 and c-1 run under the fit of chunk c.  The fits are
@@ -121,17 +121,34 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
       fa_index, mask: host arrays [nvox] or None; mask gates (mask != 0)
       mask_values  host array [nvox]: the driver's preparation on the device -- every echo is multiplied by it and negative values are
                 clipped to 0 (motor:180-182, :279) before anything else sees the chunk
+      device_data  instead of host_data (pass None for it): the prepared voxel list already ON THE DEVICE ([nvox, n_te], or [n_te, nvox] with
+                echo_major=True) -- what is left of the driver after a whole-volume filter (TV, NESMA, FA smoothing).  Nothing is uploaded but
+                the per-voxel arrays; the chunks are cut out of it in place and only the output side of the pipeline overlaps with the fits.
+                device_fa_data: the same list as the FA step shall see it (the Gaussian-smoothed volume, motor:337-343); default: device_data
       out       a dict this function returned earlier for the same shapes: its pinned buffers are written again (pinning 0.8 GB of
                 host memory costs tens of ms; torch's caching host allocator does the same for buffers that were freed)
     Returns pinned CPU tensors: fsol [nvox, n_t2], sig [nvox, n_te], reg [nvox], maps [6, nvox], status [nvox] (int32), fa_index
     [nvox], fa_gate [nvox] (1 where the FA step's gate holds, fa_estimation.py:45: mask and a positive echo sum) and lam when asked;
     chunking changes nothing in them (every voxel is solved on its own)."""
     dev = plan.device
-    src = host_data if torch.is_tensor(host_data) else torch.from_numpy(host_data)
     nte, nt2 = plan.n_te, plan.n_t2
-    ok_shape = src.dim() == 2 and src.shape[0 if echo_major else 1] == nte
-    if src.is_cuda or src.dtype != torch.float64 or not ok_shape or not src.is_contiguous():
-        raise ValueError("host_data must be a contiguous float64 %s array in host memory" % ("[n_te=%d, nvox]" % nte if echo_major else "[nvox, n_te=%d]" % nte))
+    want_shape = "[n_te=%d, nvox]" % nte if echo_major else "[nvox, n_te=%d]" % nte
+    on_device = device_data is not None
+    if on_device:
+        if host_data is not None or mask_values is not None:
+            raise ValueError("device_data stands in for host_data and is already prepared (no mask_values)")
+        src = device_data
+        for t in (src,) if device_fa_data is None else (src, device_fa_data):
+            if not (torch.is_tensor(t) and t.device == dev and t.dtype == torch.float64 and t.dim() == 2 and t.shape[0 if echo_major else 1] == nte
+                    and t.is_contiguous() and t.shape == src.shape):
+                raise ValueError("device_data / device_fa_data must be contiguous float64 %s tensors on %s" % (want_shape, dev))
+    else:
+        if device_fa_data is not None:
+            raise ValueError("device_fa_data goes with device_data")
+        src = host_data if torch.is_tensor(host_data) else torch.from_numpy(host_data)
+        ok_shape = src.dim() == 2 and src.shape[0 if echo_major else 1] == nte
+        if src.is_cuda or src.dtype != torch.float64 or not ok_shape or not src.is_contiguous():
+            raise ValueError("host_data must be a contiguous float64 %s array in host memory" % want_shape)
     nvox = int(src.shape[1 if echo_major else 0])
     chunk = max(1, min(int(chunk), max(nvox, 1)))
     nch = (nvox + chunk - 1) // chunk
@@ -148,23 +165,28 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
         res[name] = t if ok else pin(shp, dt)
     if nvox == 0:
         return res
-    as1d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(dt, copy=False)))
+    # the per-voxel host arrays go through PINNED copies: an H2D copy from pageable memory is not asynchronous -- it waits on the host for
+    # everything its stream waits for, here the fit of chunk c - 2 (measured: up to 56 ms of the host standing in a 2 MB copy)
+    def as1d(a, dt):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(dt, copy=False)))
+        return pin(t.shape, t.dtype).copy_(t)
     fa_h = None if fa_index is None else as1d(fa_index, np.float64)
-    mk_h = None if mask is None else torch.from_numpy(np.ascontiguousarray((np.asarray(mask).reshape(-1) != 0).astype(np.uint8)))
+    mk_h = None if mask is None else as1d(np.asarray(mask).reshape(-1) != 0, np.uint8)
     mv_h = None if mask_values is None else as1d(mask_values, np.float64)
     in_shape = (nte, chunk) if echo_major else (chunk, nte)
-    stage = None if src.is_pinned() else [pin(in_shape), pin(in_shape)]
+    stage = None if (on_device or src.is_pinned()) else [pin(in_shape), pin(in_shape)]
     dv = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, device=dev)
     cut = (lambda t, n: t[:, :n]) if echo_major else (lambda t, n: t[:n])         # the first n voxels of a chunk buffer
     with torch.cuda.device(dev):
         s_in, s_fit, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        d_in = [dv(in_shape), dv(in_shape)]
+        d_in = [None, None] if on_device else [dv(in_shape), dv(in_shape)]
         d_fa = [dv((chunk,)), dv((chunk,))]
         d_gate = [dv((chunk,)), dv((chunk,))]
         d_mk = [dv((chunk,), torch.uint8), dv((chunk,), torch.uint8)] if mk_h is not None else [None, None]
         d_mv = [dv((chunk,)), dv((chunk,))] if mv_h is not None else [None, None]
         d_out = [{"fsol": dv((chunk, nt2)), "sig": dv((chunk, nte)), "reg": dv((chunk,)), "lam": dv((chunk,)), "maps": dv((6, chunk)),
                   "status": dv((chunk,), torch.int32)} for _ in range(2)]
+        ones_te = torch.ones(nte, dtype=torch.float64, device=dev)
         ev_in = [torch.cuda.Event(), torch.cuda.Event()]
         ev_fit = [torch.cuda.Event(), torch.cuda.Event()]
         ev_out = [torch.cuda.Event(), torch.cuda.Event()]
@@ -174,7 +196,7 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
             k = c & 1
             lo, hi = c * chunk, min(nvox, (c + 1) * chunk)
             n = hi - lo
-            h = src[:, lo:hi] if echo_major else src[lo:hi]
+            h = None if on_device else (src[:, lo:hi] if echo_major else src[lo:hi])
             if stage is not None:
                 if c >= 2:
                     ev_in[k].synchronize()          # the H2D of chunk c - 2 has left this staging buffer (it finished before that chunk's fit began)
@@ -184,7 +206,8 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                 if c >= 2:                          # the device slot is free once chunk c - 2 has been fitted and its outputs (fa_index) copied out:
                     s_in.wait_event(ev_fit[k])      # waited for on the GPU, not by the host -- the host goes on staging while the GPU fits
                     s_in.wait_event(ev_out[k])
-                cut(d_in[k], n).copy_(h, non_blocking=True)
+                if not on_device:
+                    cut(d_in[k], n).copy_(h, non_blocking=True)
                 if fa_h is not None:
                     d_fa[k][:n].copy_(fa_h[lo:hi], non_blocking=True)
                 if mk_h is not None:
@@ -204,19 +227,22 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
                     if c >= 2:
                         s_fit.wait_event(ev_out[k])     # the outputs of chunk c - 2 have left this slot
                     o = d_out[k]
-                    raw = cut(d_in[k], n)
+                    raw = (src[:, lo:hi] if echo_major else src[lo:hi]) if on_device else cut(d_in[k], n)
                     if mv_h is not None:                # motor:180-182, :279 on the device, in place
                         raw.mul_(d_mv[k][:n].unsqueeze(0) if echo_major else d_mv[k][:n].unsqueeze(1))
                         raw.clamp_(min=0.0)
-                    dd = raw.t() if echo_major else raw # [n, n_te] either way (echo-major: a strided view, read in place when the chunk is full)
+                    dd = raw.t() if echo_major else raw # [n, n_te] either way (echo-major: a strided view, read in place)
+                    dd_fa = dd                          # what the FA step sees (fa_estimation.py:45 gates on ITS echo sum)
+                    if device_fa_data is not None:
+                        dd_fa = device_fa_data[:, lo:hi].t() if echo_major else device_fa_data[lo:hi]
                     mk = None if mk_h is None else d_mk[k][:n]
-                    gate = dd.sum(dim=1) > 0
+                    gate = torch.mv(dd_fa, ones_te) > 0  # the echo sum as a matrix-vector product: torch's row reduction of a [n, 32] array took 1.6 ms per chunk, this 0.1
                     d_gate[k][:n].copy_(gate if mk is None else (gate & (mk != 0)))
                     if fa_method == "brute-force":
-                        fa, _, _ = plan.fa_bruteforce(dd, mk)
+                        fa, _, _ = plan.fa_bruteforce(dd_fa, mk)
                         d_fa[k][:n].copy_(fa)
                     elif callable(fa_method):
-                        d_fa[k][:n].copy_(fa_method(dd, mk))
+                        d_fa[k][:n].copy_(fa_method(dd_fa, mk))
                     elif fa_h is None:
                         d_fa[k][:n].zero_()
                     # the chunk's maps are [6, n]: a contiguous [6 * n] prefix of the slot's buffer viewed as [6, n]
@@ -332,6 +358,10 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
         if len(vol_shape) != 3:
             raise ValueError("FA_smooth='yes' needs data [nx,ny,nz,nt]")
         dd_fa = gaussian_smooth(dd, 2.0)
+    if not distributed and not return_prepared and data.ndim >= 2 and ONE_SHOT_PIPELINE:
+        # the filters needed the whole volume; the FA step and the fit do not: chunks of the device-resident voxel list, outputs copied out under the fits
+        return _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, device, plan, True,
+                                on_device=(dd, dd_fa if dd_fa is not dd else None))
     mm = (mk > 0)
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
@@ -366,19 +396,38 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
             plan.close()
 
 
+ONE_SHOT_PIPELINE = True      # denoised / FA-smoothed runs: the fit is chunked over the device-resident volume and the outputs leave under it (False: one fit call, then .cpu())
 PIPELINE_CHUNK = 262144       # voxels per chunk of the driver's host pipeline (67 MB in, 200 MB out at 32 echoes / 60 bins; measured 65 536 / 131 072 / 262 144: 207 / 170-190 / 165 ms per Mi voxels)
 
 
-def _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, device, plan, prepared):
+def _match_layout(t, order):
+    """the volume tensor t [..., nt] laid out in memory as `order` says ('C', or 'F': the reversed axes contiguous)"""
+    rev = list(reversed(range(t.dim())))
+    if order == "C":
+        return t.contiguous()
+    return t if t.permute(*rev).is_contiguous() else t.permute(*rev).contiguous().permute(*rev)
+
+
+def _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, device, plan, prepared, on_device=None):
     """recon_met2_arrays without denoising or FA smoothing (nothing needs the whole volume at once): the host volume streams through
     fit_host_pipeline in its own memory order -- C-ordered [.., nt] voxel-major, Fortran-ordered (nibabel's) echo-major -- and the
     outputs land in pinned host buffers that are returned as numpy views, reshaped to the volume.  Same numbers as the one-shot
-    path (`test_driver_pipeline_equals_one_shot`)."""
-    from .plan import unflatten
+    path (`test_driver_pipeline_equals_one_shot`).
+    on_device = (dd, dd_fa or None): the prepared (and filtered) volume as a tensor on the device, and the smoothed one the FA step shall
+    see -- the part of a denoised / FA-smoothed run that comes after its whole-volume filters; `data` then only gives the shape."""
+    from .plan import unflatten, voxel_layout
     vol_shape = data.shape[:-1]
     nt = data.shape[-1]
     nvox = int(np.prod(vol_shape))
     order = "C" if data.flags.c_contiguous else "F"
+    dev_src = dev_fa = None
+    if on_device is not None:
+        dd, dd_fa = on_device
+        dd, _, _, _, _, order = voxel_layout(dd, nt)
+        rev = list(reversed(range(dd.dim())))
+        flat2 = (lambda t: t.reshape(nvox, nt)) if order == "C" else (lambda t: t.permute(*rev).reshape(nt, nvox))
+        dev_src = flat2(dd)
+        dev_fa = None if dd_fa is None else flat2(_match_layout(dd_fa, order))
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
     Npc = 96 if reg_method == "T2SPARC" else 60
@@ -386,7 +435,9 @@ def _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method
     T1s = 1000.0 * np.ones_like(T2s)
     alpha_values = np.linspace(90.0, 180.0, 91 * 3 if FA_method == "spline" else 91)      # motor:231-244
     flat = (lambda a: np.asarray(a).reshape(-1, order=order))                               # per-voxel arrays in the data's voxel order
-    src = data.reshape(nvox, nt) if order == "C" else data.reshape(nvox, nt, order="F").T   # views: [nvox, nt] or echo-major [nt, nvox]
+    src = None
+    if on_device is None:
+        src = data.reshape(nvox, nt) if order == "C" else data.reshape(nvox, nt, order="F").T   # views: [nvox, nt] or echo-major [nt, nvox]
     mvals = None if prepared else flat(mask).astype(np.float64)
     own = plan is None
     plan_lr = None
@@ -405,7 +456,8 @@ def _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method
             else:
                 fa_m = "brute-force"
         out = fit_host_pipeline(plan, reg_method, src, fa_method=fa_m, fa_index=None if fa_index is None else flat(fa_index),
-                                mask=flat(mask) > 0, chunk=PIPELINE_CHUNK, echo_major=(order == "F"), mask_values=mvals)
+                                mask=flat(mask) > 0, chunk=PIPELINE_CHUNK, echo_major=(order == "F"), mask_values=mvals,
+                                device_data=dev_src, device_fa_data=dev_fa)
         vol = lambda t, lead=0: unflatten(t, vol_shape, order, lead=lead).numpy()
         res = {"fsol_4D": vol(out["fsol"]), "Est_Signal": vol(out["sig"]), "reg_param": vol(out["reg"]), "FA_index": vol(out["fa_index"])}
         fitted_fa = vol(out["fa_gate"]) > 0                    # gate of the FA step (fa_estimation.py:45), formed on the prepared chunk

@@ -28,7 +28,8 @@ def voxel_layout(data, n_te):
     """(tensor, nvox, voxel_stride, echo_stride, vol_shape) for the strided C entries: `data` is [..., n_te] (any number of
     leading voxel axes).  C-contiguous input -> strides (n_te, 1), voxels in C order.  Fortran-contiguous input (what nibabel
     hands the reference's driver, motor:167-173) -> strides (1, nvox), voxels in Fortran order: no copy, outputs come back in
-    that voxel order (`unflatten` puts them into the volume's shape).  Any other layout is made C-contiguous (one copy)."""
+    that voxel order (`unflatten` puts them into the volume's shape).  A 2-D voxel list with any positive strides (a slice of a larger
+    list) is read in place as well.  Any other layout is made C-contiguous (one copy)."""
     if data.dim() < 2 or data.shape[-1] != n_te:
         raise ValueError("data must be [..., n_te=%d], got %s" % (n_te, tuple(data.shape)))
     vol = tuple(data.shape[:-1])
@@ -39,6 +40,8 @@ def voxel_layout(data, n_te):
         return data, nvox, n_te, 1, vol, "C"
     if data.permute(*reversed(range(data.dim()))).is_contiguous():       # (also an echo-major voxel list: a transposed [n_te, nvox] array)
         return data, nvox, 1, nvox, vol, "F"
+    if data.dim() == 2 and data.stride(0) > 0 and data.stride(1) > 0:    # a run of voxels cut out of a larger list (either layout): the C entries take any strides
+        return data, nvox, int(data.stride(0)), int(data.stride(1)), vol, "C"
     return data.contiguous(), nvox, n_te, 1, vol, "C"
 
 

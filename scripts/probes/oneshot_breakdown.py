@@ -1,0 +1,28 @@
+"""Wall-clock breakdown of recon_met2_arrays' one-shot path (denoise='TV', FA_smooth='yes', spline) on the 128x128x64x32 phantom."""
+import importlib, json, sys, time, math
+import numpy as np, torch
+sys.path.insert(0, ".")
+PKG = "multicomponent-t2-toolbox_amd"
+motor = importlib.import_module(PKG + ".motor"); synth = importlib.import_module(PKG + ".synth"); pkg = importlib.import_module(PKG)
+dims = (128, 128, 64); nte, nt2 = 32, 60
+vol, mask = synth.make_phantom(dims, nte=nte, device="cuda:0")
+host = vol.cpu().numpy(); hmask = mask.cpu().numpy().astype(np.int64)
+dev = torch.device("cuda", 0)
+def tick(label, t0):
+    torch.cuda.synchronize(); t = time.perf_counter(); print("%-40s %7.1f ms" % (label, (t - t0) * 1e3)); return t
+for rep in range(3):
+    print("--- rep", rep)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); tA = t0
+    dd, mk = motor._prepare_volume(host, hmask, dev, False, "TV"); t0 = tick("H2D + mask + clip + TV", t0)
+    dd_fa = motor.gaussian_smooth(dd, 2.0); t0 = tick("gaussian", t0)
+    T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=60); T1s = 1000.0 * np.ones_like(T2s)
+    alpha = np.linspace(90.0, 180.0, 273)
+    plan = pkg.Met2Plan(nte, 60, 273); plan.build_dictionary_epg(T2s, T1s, 10.0, alpha, 3000.0); plan.set_penalty("L2", T2s); t0 = tick("plan", t0)
+    mm = mk > 0
+    fa_vol = motor._estimate_fa(plan, dd_fa, mm, "spline", None, T2s, T1s, 10.0, 3000.0, alpha, 0); t0 = tick("FA spline", t0)
+    out = plan.fit("X2", dd, fa_index=fa_vol, mask=mm); t0 = tick("fit", t0)
+    res = {"fsol_4D": out["fsol"].cpu().numpy(), "Est_Signal": out["sig"].cpu().numpy(), "reg_param": out["reg"].cpu().numpy(), "FA_index": fa_vol.cpu().numpy()}
+    maps = out["maps"].cpu().numpy(); t0 = tick("D2H (.cpu().numpy())", t0)
+    plan.close(); t0 = tick("close", t0)
+    print("total %.1f ms" % ((t0 - tA) * 1e3))
+    t0 = time.perf_counter(); x = torch.as_tensor(host, device=dev); t0 = tick("  plain H2D of the volume", t0)

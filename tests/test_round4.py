@@ -440,3 +440,41 @@ def test_bench_tv_workload_line():
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 0
     assert "UNPINNED" in line["parity"]["against"] and line["parity"]["max_rel"] <= 1e-12
     assert line["parity"]["iterations_hip_oracle"][0] == line["parity"]["iterations_hip_oracle"][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order,denoise,smooth,fa_method", [("C", "TV", "yes", "spline"), ("F", "TV", "yes", "spline"), ("F", "NESMA", "no", "brute-force"),
+                                                            ("C", "None", "yes", "brute-force"), ("F", "None", "yes", "spline")])
+def test_filtered_runs_are_chunked_on_the_device(order, denoise, smooth, fa_method):
+    # A denoised or FA-smoothed run filters the whole volume on the device, then feeds the FA step and the fit in chunks of the device-resident
+    # voxel list while the outputs of earlier chunks are copied out (motor._recon_pipelined, on_device); return_prepared=True keeps the one-call
+    # path.  Same ten outputs bit for bit, both memory orders, ragged last chunk, zero / non-unit mask values, negative samples.
+    motor = importlib.import_module(PKG + ".motor")
+    synth = importlib.import_module(PKG + ".synth")
+    dims = (14, 12, 13)
+    nvox = int(np.prod(dims))
+    alphas = np.linspace(90.0, 180.0, 91)
+    data, _, _ = synth.make_voxels(nvox, nte=32, seed=91, fa_values=alphas, device="cuda")
+    vol = data.cpu().numpy().reshape(dims + (32,))
+    rng = np.random.default_rng(5)
+    vol[rng.integers(0, 14, 20), rng.integers(0, 12, 20), rng.integers(0, 13, 20), rng.integers(0, 32, 20)] *= -1.0
+    mask = np.ones(dims, dtype=np.int64); mask[::5, ::3, :] = 0; mask[1, 1, 1] = 2
+    if order == "F":
+        vol = np.asfortranarray(vol)
+    TE = 10.0 * np.arange(1, 33)
+    keep = motor.PIPELINE_CHUNK
+    try:
+        motor.PIPELINE_CHUNK = 700                                  # 2184 voxels -> four chunks, the last one ragged
+        got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth)
+    finally:
+        motor.PIPELINE_CHUNK = keep
+    ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
+    for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
+        assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), k
+    # ... and the switch back to the one-call path gives the same again
+    try:
+        motor.ONE_SHOT_PIPELINE = False
+        one = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth)
+    finally:
+        motor.ONE_SHOT_PIPELINE = True
+    assert np.array_equal(one["MWF"], got["MWF"], equal_nan=True) and np.array_equal(one["FA_index"], got["FA_index"])
