@@ -23,7 +23,7 @@ for fa_method, smooth, fa_idx in (("brute-force", "no", fa_known), ("spline", "y
         best = dt if (best is None or rep == 1) else min(best, dt)          # the first call of a kind pins its buffers: best of the later three
     dt = best
     print(json.dumps({"driver": "recon_met2_arrays", "dims": dims, "FA_method": "given (single FA)" if fa_idx is not None else fa_method, "FA_smooth": smooth,
-                      "path": "one-shot (whole volume on the device)" if smooth == "yes" else "chunked host pipeline", "seconds": dt,
+                      "path": "filters on the device, then the chunk loop on the device-resident volume" if smooth == "yes" else "chunked host pipeline", "seconds": dt,
                       "voxels_per_s": nvox / dt, "MWF_mean": float(res["MWF"].mean())}))
 d4 = torch.as_tensor(data, device="cuda")
 motor.gaussian_smooth(d4, 2.0); torch.cuda.synchronize(); t0 = time.perf_counter()
