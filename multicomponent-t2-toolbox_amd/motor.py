@@ -107,6 +107,29 @@ def gaussian_smooth(data, sigma=2.0, truncate=4.0, device=0):
     return out.cpu().numpy() if as_numpy else out
 
 
+_COPY_POOL = None
+
+
+def _host_copy(dst, src):
+    """dst <- src, two CPU tensors of one shape (dst pinned): numpy's memcpy on four plain threads.  NOT Tensor.copy_: torch spreads a large CPU
+    copy over its intra-op pool -- one thread per core of the machine -- whose workers spin after every parallel region; inside a container with a CPU
+    quota (this GPU box: 16 of 256 cores) that burns the quota within the scheduler period and the whole process is throttled until the next one:
+    measured, the driver's host thread stood 60-100 ms at a time in whichever call it was in (a 17 MB memcpy, an event wait)."""
+    global _COPY_POOL
+    d, s = dst.numpy(), src.numpy()
+    if d.nbytes < (4 << 20) or d.shape[0] < 4:
+        np.copyto(d, s)
+        return dst
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="met2-stage")
+    n0 = d.shape[0]
+    cuts = [n0 * i // 4 for i in range(5)]
+    for f in [_COPY_POOL.submit(np.copyto, d[a:b], s[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]:
+        f.result()
+    return dst
+
+
 def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None, mask=None, chunk=262144, want_lambda=False, out=None,
                       echo_major=False, mask_values=None, device_data=None, device_fa_data=None):
     """Driver steps 2-4 (motor:349-373, 427-472) for a voxel list that lives in HOST memory, as the reference's driver holds it
@@ -169,7 +192,7 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
     # everything its stream waits for, here the fit of chunk c - 2 (measured: up to 56 ms of the host standing in a 2 MB copy)
     def as1d(a, dt):
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1).astype(dt, copy=False)))
-        return pin(t.shape, t.dtype).copy_(t)
+        return _host_copy(pin(t.shape, t.dtype), t)
     fa_h = None if fa_index is None else as1d(fa_index, np.float64)
     mk_h = None if mask is None else as1d(np.asarray(mask).reshape(-1) != 0, np.uint8)
     mv_h = None if mask_values is None else as1d(mask_values, np.float64)
@@ -200,7 +223,7 @@ def fit_host_pipeline(plan, reg_method, host_data, fa_method=None, fa_index=None
             if stage is not None:
                 if c >= 2:
                     ev_in[k].synchronize()          # the H2D of chunk c - 2 has left this staging buffer (it finished before that chunk's fit began)
-                cut(stage[k], n).copy_(h)           # pageable -> pinned (host memcpy, one segment per echo when echo-major)
+                _host_copy(cut(stage[k], n), h)     # pageable -> pinned (host memcpy, one segment per echo when echo-major)
                 h = cut(stage[k], n)
             with torch.cuda.stream(s_in):
                 if c >= 2:                          # the device slot is free once chunk c - 2 has been fitted and its outputs (fa_index) copied out:

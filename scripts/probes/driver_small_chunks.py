@@ -1,0 +1,39 @@
+"""Where the host stands when the driver's chunks are small (65 536 voxels): timed Tensor.copy_, Event.synchronize, Event.wait, plan calls."""
+import importlib, sys, time, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+PKG = "multicomponent-t2-toolbox_amd"
+motor = importlib.import_module(PKG + ".motor"); synth = importlib.import_module(PKG + ".synth"); planm = importlib.import_module(PKG + ".plan")
+vol, mask = synth.make_phantom((128, 128, 64), nte=32, device="cuda:0")
+host = vol.cpu().numpy(); hmask = mask.cpu().numpy().astype(np.int64)
+TE = 10.0 * np.arange(1, 33)
+motor.PIPELINE_CHUNK = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+run = lambda: motor.recon_met2_arrays(host, hmask, TE, 3000.0, "X2", "L2", "spline", 40.0)
+for _ in range(2):
+    r = run(); r = None
+log = []
+def wrap(obj, name, label):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k)
+        lab = label
+        if label == "copy_":
+            lab = "copy_ %s<-%s %.1fMB" % (a[0].device.type, a[1].device.type, a[0].numel() * a[0].element_size() / 1e6)
+        log.append((lab, (time.perf_counter() - t0) * 1e3, t0)); return r
+    setattr(obj, name, g)
+wrap(torch.Tensor, "copy_", "copy_"); wrap(torch.cuda.Event, "synchronize", "Event.synchronize"); wrap(torch.cuda.Event, "wait", "Event.wait")
+wrap(torch.cuda.Event, "record", "Event.record"); wrap(torch.cuda.Stream, "wait_event", "Stream.wait_event"); wrap(torch.cuda.Stream, "synchronize", "Stream.synchronize")
+for n in ("fa_spline", "fit", "finish"):
+    wrap(planm.Met2Plan, n, n)
+wrap(torch, "mv", "mv"); wrap(torch.Tensor, "mul_", "mul_"); wrap(torch.Tensor, "clamp_", "clamp_")
+torch.cuda.synchronize(); t0 = time.perf_counter(); r = run(); torch.cuda.synchronize(); t1 = time.perf_counter()
+print("wall %.1f ms, chunk %d" % ((t1 - t0) * 1e3, motor.PIPELINE_CHUNK))
+agg = {}
+for l, ms, ts in log:
+    a = agg.setdefault(l, [0.0, 0, 0.0]); a[0] += ms; a[1] += 1; a[2] = max(a[2], ms)
+for l, (t, c, mx) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print("  %-20s %8.2f ms  %4d calls  max %.2f" % (l, t, c, mx))
+print("calls over 3 ms:")
+for l, ms, ts in log:
+    if ms > 3.0:
+        print("   +%7.1f  %-20s %7.2f ms" % ((ts - t0) * 1e3, l, ms))

@@ -1,11 +1,12 @@
-"""Runs recon_met2_arrays three times (settings from argv) for a rocprofv3 --kernel-trace --memory-copy-trace timeline."""
-import importlib, sys, time
+"""Runs recon_met2_arrays three times (settings from argv: denoise fa_method FA_smooth [chunk]) for a rocprofv3 --kernel-trace --memory-copy-trace timeline."""
+import importlib, sys, time, os
 import numpy as np, torch
-import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 PKG = "multicomponent-t2-toolbox_amd"
 motor = importlib.import_module(PKG + ".motor"); synth = importlib.import_module(PKG + ".synth")
-denoise, fa_method, smooth = (sys.argv[1:4] + ["None", "spline", "no"][len(sys.argv) - 1:])[:3]
+denoise, fa_method, smooth = (sys.argv[1:4] + ["None", "spline", "no"][len(sys.argv[1:4]):])[:3]
+if len(sys.argv) > 4:
+    motor.PIPELINE_CHUNK = int(sys.argv[4])
 vol, mask = synth.make_phantom((128, 128, 64), nte=32, device="cuda:0")
 host = vol.cpu().numpy(); hmask = mask.cpu().numpy().astype(np.int64)
 TE = 10.0 * np.arange(1, 33)
