@@ -19,12 +19,13 @@
  *   - a plan may be used from one host thread at a time and serves one stream at a time (its sort scratch, error word and
  *     timing events are per plan: a fit or met2_plan_finish on another stream while enqueued fits are pending returns
  *     MET2_E_STATE); different plans may be used concurrently, on one device or on several;
- *   - multi-GPU: the library keeps no global state besides the calling thread's error message,
- *     so the multi-GPU driver is "one plan per device (met2_options.device), each driven by its own host thread or process,
- *     all at once": dist.py does that with one process per GPU under torch.distributed,
- *     tests/test_round4.py::test_two_host_threads_two_plans_run_concurrently with two threads.  The path's single collective --
- *     the gather of the outputs to the root -- belongs to the host's communicator (RCCL through torch.distributed), so there is
- *     deliberately no multi-device entry behind this C ABI.
+ *   - multi-GPU: the library keeps no global state besides the calling thread's error message and
+ *     what met2_fit_host parks with a plan, so "one plan per device (met2_options.device), each driven by its own host thread or
+ *     process, all at once" works from any host language.  Two drivers are built on it:
+ *       met2_fit_host (ABI 5, below)  ONE process, one host thread per plan inside the call, host arrays in and out -- what the
+ *                                     reference's single Python process binds; no communicator, the outputs meet in host memory;
+ *       dist.py                       one process per GPU under torch.distributed; the path's single collective -- the gather of
+ *                                     the outputs to the root -- belongs to the host's communicator (RCCL).
  */
 #ifndef MET2_HIP_H
 #define MET2_HIP_H
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MET2_ABI_VERSION 4
+#define MET2_ABI_VERSION 5
 
 /* reg_method of motor/motor_recon_met2_real_data.py:134-150 */
 enum met2_method {
@@ -98,6 +99,8 @@ int met2_plan_destroy(met2_plan *plan);
  * (the per-call arguments `factor` of nnls_x2 and `reg_opt` of nnls_tik, algorithms.py:211,262) */
 int met2_plan_set_options(met2_plan *plan, const met2_options *opt);
 int met2_plan_get_options(met2_plan *plan, met2_options *opt);
+/* the shape the plan was created with (any of the three may be NULL) */
+int met2_plan_get_shape(met2_plan *plan, int32_t *n_te, int32_t *n_t2, int32_t *n_fa);
 
 /* epg/epg.py:155 create_Dic_3D -- EPG dictionary built on the device, one wave per
  * (T2, flip angle).  T2s/T1s [n_t2], alpha_deg [n_fa] are host arrays.  Also forms the
@@ -169,6 +172,37 @@ int met2_fit_enqueue_strided(met2_plan *plan, int32_t method, int64_t nvox, cons
                              int64_t echo_stride, const double *fa_index, const uint8_t *mask, double *fsol, double *sig,
                              double *reg, double *lam, double *maps, int32_t *status, void *stream);
 int met2_plan_finish(met2_plan *plan, void *stream);
+
+/* ---- host to host, one or several devices (ABI 5) ----------------------------------------
+ * motor:349-373 + motor:427-472 for a voxel list that lives in HOST memory, as the reference's driver holds it (motor:167-182), from ONE
+ * process: what a binding of the reference calls instead of its joblib loop over image rows (motor:427-441) -- numpy arrays in, numpy
+ * arrays out, no device memory, stream or communicator on the caller's side.
+ *   plans [n_plans]   1..64 distinct plans of one shape, configured alike (dictionary, penalty, options), each on the device of its
+ *                     met2_options.device; several plans may share a device.  The voxel list is cut into blocks of `chunk` voxels
+ *                     and block b is fitted by plan b mod n_plans (interleaved: tissue classes cluster in space and differ 10x in
+ *                     iteration count).  Every plan is driven by its own host thread inside the call (one plan:
+ *                     the calling thread) through three streams of its device: H2D of its block c + 1 | [FA estimation and] fit of
+ *                     block c | D2H of block c - 1.  There is no exchange between devices.
+ *   ALL array arguments are HOST pointers; arrays in pinned memory (hipHostMalloc, hipHostRegister) are copied from / to in place,
+ *   pageable ones are staged through pinned block buffers by the plan's thread while its device works:
+ *   data              echo e of voxel v at data[v * voxel_stride + e * echo_stride] (strides in doubles, > 0): [nvox][n_te] rows
+ *                     (echo_stride 1) and the Fortran-ordered volume of nibabel (voxel_stride 1, echo_stride nvox) are copied as they
+ *                     lie and read in place on the device; any other layout is gathered on the host
+ *   fa_index, mask    [nvox] float64 / uint8 as for met2_fit, NULL = flip angle 0 / all ones
+ *   estimate_fa       1: the flip angles come from the brute-force search over the plans' FA axis on every block
+ *                     (met2_fa_bruteforce, fa_estimation.py:74-111) and fa_index must be NULL; 0: they are given
+ *   fsol [nvox][n_t2], sig [nvox][n_te], reg, lam [nvox], maps [6][nvox], status [nvox]   as for met2_fit (sig, lam, maps, status may be NULL)
+ *   fa_out [nvox]     out, may be NULL: the FA index every voxel was fitted with
+ *   chunk             voxels per block; 0 = a quarter of a plan's share, in multiples of 4 096, at most 262 144
+ *   plan_ms [n_plans] out, may be NULL: wall-clock ms every plan's thread spent in the call
+ * Blocking.  Every voxel is solved on its own, so the outputs are bit for bit those of one met2_fit over the whole list, whatever
+ * n_plans, chunk and the devices.  Returns the first failing plan's code (an FA index outside the dictionary: MET2_E_INVALID) after
+ * ALL plans' streams have drained -- nothing writes to the caller's arrays after the return.  The block buffers (two slots of
+ * chunk x ~8 (2 n_te + n_t2 + 10) bytes on the device, the same pinned when a pageable array takes part), three streams and six
+ * events stay with each plan until met2_plan_destroy. */
+int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
+                  int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol, double *sig,
+                  double *reg, double *lam, double *maps, int32_t *status, double *fa_out, int64_t chunk, double *plan_ms);
 
 /* Test/diagnostic entry: `method` = 10 + MET2_X2 / MET2_GCV / MET2_BAYESREG passed to met2_fit
  * evaluates that method's lambda-selection objective (algorithms.py:226-233, :285-296,

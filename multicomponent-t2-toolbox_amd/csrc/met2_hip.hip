@@ -71,6 +71,7 @@ extern template int launch_fit_nb<3, 2, true>(const FitArgs &, const LaunchGeom 
 // ------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------
+namespace met2 { __attribute__((visibility("hidden"))) void host_release(met2_plan *plan); }
 static thread_local std::string g_err;
 int met2::abi_fail(int code, const std::string &msg) { g_err = msg; return code; }
 
@@ -1502,9 +1503,19 @@ int met2_plan_get_options(met2_plan *p, met2_options *opt)
     return MET2_OK;
 }
 
+int met2_plan_get_shape(met2_plan *p, int32_t *n_te, int32_t *n_t2, int32_t *n_fa)
+{
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    if (n_te) *n_te = p->n_te;
+    if (n_t2) *n_t2 = p->n_t2;
+    if (n_fa) *n_fa = p->n_fa;
+    return MET2_OK;
+}
+
 int met2_plan_destroy(met2_plan *p)
 {
     if (!p) return MET2_OK;
+    met2::host_release(p);           // what met2_fit_host keeps with the plan (met2_host.hip)
     DevGuard dev_guard_(p->opt.device);
     void *bufs[] = {p->dQt, p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
     for (void *b : bufs) (void)hipFree(b);
