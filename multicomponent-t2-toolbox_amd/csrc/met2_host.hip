@@ -13,6 +13,7 @@
 // No kernels in this file: it is the host side of the boundary, in C++ because the boundary is a C ABI (no torch, no Python).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -116,7 +117,7 @@ struct Job {
     const double *data; int64_t vs, es;
     const double *fa_index; const uint8_t *mask; int estimate_fa;
     double *fsol, *sig, *reg, *lam, *maps; int32_t *status; double *fa_out;
-    int64_t chunk; int nte, nt2;
+    int64_t chunk; int nte, nt2; bool split;
     // which host arrays the device reaches directly
     bool pin_data, pin_fa, pin_mask, pin_fsol, pin_sig, pin_reg, pin_lam, pin_maps, pin_status, pin_fa_out;
     int in_case;              // 0: voxel-major rows (es == 1), 1: echo-major (vs == 1), 2: general strides (gathered on the host)
@@ -169,10 +170,22 @@ int pipeline(const Job &J, int t, Work *w)
     const int nte = J.nte, nt2 = J.nt2;
     const int64_t chunk = J.chunk;
     const int64_t nblocks = (J.nvox + chunk - 1) / chunk;
-    const int64_t mine = nblocks > t ? (nblocks - t + J.n_plans - 1) / J.n_plans : 0;
+    // this plan's pieces of the voxel list: its blocks, with the first one split 1/8 + 7/8 and the last one 7/8 + 1/8 -- the upload of the
+    // very first piece and the download of the very last one are the only copies that do not run under a fit, so they are made short
+    // (configs[1], one plan, four blocks of 262 144: 166.7 -> see DESIGN section 7; a piece costs ~1.9 ms of queue tail and sort passes)
+    std::vector<std::pair<int64_t, int64_t>> seg;           // (first voxel, voxels)
+    for (int64_t b = t; b < nblocks; b += J.n_plans) seg.emplace_back(b * chunk, std::min<int64_t>(chunk, J.nvox - b * chunk));
+    if (J.split && !seg.empty()) {
+        auto eighth = [](int64_t n) { return n >= 32768 ? std::max<int64_t>(4096, (n / 8) & ~(int64_t)4095) : 0; };
+        {   const auto last = seg.back(); const int64_t e = eighth(last.second);
+            if (e) { seg.back() = {last.first, last.second - e}; seg.emplace_back(last.first + last.second - e, e); } }
+        {   const auto first = seg.front(); const int64_t e = eighth(first.second);
+            if (e) { seg.front() = {first.first + e, first.second - e}; seg.insert(seg.begin(), {first.first, e}); } }
+    }
+    const int64_t mine = (int64_t)seg.size();
     const Layout L(w->cap, nte, nt2);
-    auto lo_of = [&](int64_t c) { return (t + c * J.n_plans) * chunk; };
-    auto n_of = [&](int64_t c) { return std::min<int64_t>(chunk, J.nvox - lo_of(c)); };
+    auto lo_of = [&](int64_t c) { return seg[(size_t)c].first; };
+    auto n_of = [&](int64_t c) { return seg[(size_t)c].second; };
     const bool stage_in = !J.pin_data || J.in_case == 2;
     // the block on the device: voxel-major [n][nte] (cases 0 and 2) or echo-major [nte][n] (case 1); read in place either way
     const bool dev_echo_major = J.in_case == 1;
@@ -373,6 +386,7 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     J.plans = plans; J.n_plans = n_plans; J.method = method; J.nvox = nvox; J.data = data; J.vs = voxel_stride; J.es = echo_stride;
     J.fa_index = fa_index; J.mask = mask; J.estimate_fa = estimate_fa; J.fsol = fsol; J.sig = sig; J.reg = reg; J.lam = lam; J.maps = maps;
     J.status = status; J.fa_out = fa_out; J.chunk = chunk; J.nte = nte; J.nt2 = nt2;
+    J.split = getenv("MET2_HOST_NOSPLIT") == nullptr;            // test / A-B switch: whole blocks only
     J.in_case = echo_stride == 1 ? 0 : (voxel_stride == 1 ? 1 : 2);
     if (J.in_case == 0 && voxel_stride < nte) return fail(MET2_E_INVALID, "met2_fit_host: voxel_stride < n_te with echo_stride 1 (overlapping voxels)");
     J.pin_data = is_pinned(data); J.pin_fa = is_pinned(fa_index); J.pin_mask = is_pinned(mask); J.pin_fsol = is_pinned(fsol);

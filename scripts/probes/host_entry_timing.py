@@ -2,6 +2,7 @@
 pageable arrays, default and explicit block sizes.  Prints one JSON line per case (-> profiles/r04_host_entry.jsonl)."""
 import importlib
 import json
+import os
 import sys
 import time
 
@@ -41,7 +42,10 @@ ref = None
 for k in (1, 2, 4):
     plans = make_plans(k)
     for label, src, outs in (("pinned", pin.numpy(), pinned_out), ("pageable", page, None)):
-        for chunk in (0, 65536, 262144):
+        for chunk, nosplit in ((0, False), (0, True), (65536, False), (131072, False), (262144, True)):
+            os.environ.pop("MET2_HOST_NOSPLIT", None)
+            if nosplit:
+                os.environ["MET2_HOST_NOSPLIT"] = "1"
             best = None
             for i in range(4):
                 t0 = time.perf_counter()
@@ -51,7 +55,7 @@ for k in (1, 2, 4):
                     best = dt if best is None else min(best, dt)
             if ref is None:
                 ref = outs["fsol"].copy()
-            print(json.dumps({"plans_on_one_device": k, "arrays": label, "chunk": chunk, "ms": round(1e3 * best, 2), "voxels_per_s": round(nvox / best),
+            print(json.dumps({"plans_on_one_device": k, "arrays": label, "chunk": chunk, "whole_blocks_only": nosplit, "ms": round(1e3 * best, 2), "voxels_per_s": round(nvox / best),
                               "plan_ms": [round(x, 1) for x in outs["plan_ms"]], "bit_equal": bool(np.array_equal(ref, outs["fsol"]))}), flush=True)
     for p in plans:
         p.close()

@@ -326,3 +326,30 @@ def test_ctypes_argtypes_match_the_header_prototypes():
                 assert t is C.c_double, (name, p, t)
         checked += 1
     assert checked >= 20
+
+
+def test_fit_host_argument_checks_need_no_gpu():
+    """met2_fit_host / host.fit_host reject malformed calls before anything touches a device (no compute: runs on the CPU box)"""
+    import ctypes as C
+    host = importlib.import_module(PKG + ".host")
+    lib = importlib.import_module(PKG + "._lib")
+
+    class FakePlan:                      # shape only: the checks below fail before the handle is used
+        n_te, n_t2, _h = 32, 60, C.c_void_p(0)
+
+    with pytest.raises(ValueError, match="unknown reg_method"):
+        host.fit_host(FakePlan(), "X3", np.zeros((4, 32)))
+    with pytest.raises(ValueError, match="float64"):
+        host.fit_host(FakePlan(), "X2", np.zeros((4, 32), dtype=np.float32))
+    with pytest.raises(ValueError, match="n_te=32"):
+        host.fit_host(FakePlan(), "X2", np.zeros((4, 31)))
+    with pytest.raises(ValueError, match="one entry per voxel"):
+        host.fit_host(FakePlan(), "X2", np.zeros((4, 32)), mask=np.ones(5))
+    with pytest.raises(ValueError, match="no plan"):
+        host.fit_host([], "X2", np.zeros((4, 32)))
+    L = lib.lib()
+    assert L.met2_fit_host(None, 0, 2, 0, None, 32, 1, None, None, 0, None, None, None, None, None, None, None, 0, None) == -1
+    assert b"1 to 64 plans" in L.met2_last_error()
+    arr = (C.c_void_p * 1)(None)
+    assert L.met2_fit_host(arr, 1, 2, 0, None, 32, 1, None, None, 0, None, None, None, None, None, None, None, 0, None) == -1
+    assert b"NULL plan" in L.met2_last_error()
