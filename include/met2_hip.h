@@ -188,9 +188,14 @@ int met2_plan_finish(met2_plan *plan, void *stream);
  *   data              echo e of voxel v at data[v * voxel_stride + e * echo_stride] (strides in doubles, > 0): [nvox][n_te] rows
  *                     (echo_stride 1) and the Fortran-ordered volume of nibabel (voxel_stride 1, echo_stride nvox) are copied as they
  *                     lie and read in place on the device; any other layout is gathered on the host
+ *   fa_data           NULL, or the same voxel list (same layout and strides) as the FA estimation shall see it: the Gaussian-smoothed
+ *                     volume of motor:337-343 (FA_smooth='yes', the CLI default); needs estimate_fa != 0
  *   fa_index, mask    [nvox] float64 / uint8 as for met2_fit, NULL = flip angle 0 / all ones
- *   estimate_fa       1: the flip angles come from the brute-force search over the plans' FA axis on every block
- *                     (met2_fa_bruteforce, fa_estimation.py:74-111) and fa_index must be NULL; 0: they are given
+ *   estimate_fa       0: the flip angles are given (fa_index, or angle 0);  fa_index must be NULL otherwise;
+ *                     1: brute-force search over the plans' FA axis on every block (met2_fa_bruteforce, fa_estimation.py:74-111);
+ *                     2: the spline method (fa_estimation.py:35-70, the CLI default): plain-NNLS residuals on the coarse grid of the
+ *                        plan attached with met2_plan_attach_fa_spline, a cubic spline through them, its bounded minimum snapped to the
+ *                        plans' own FA axis (met2_fa_bruteforce on the coarse plan + met2_fa_spline_select, per block)
  *   fsol [nvox][n_t2], sig [nvox][n_te], reg, lam [nvox], maps [6][nvox], status [nvox]   as for met2_fit (sig, lam, maps, status may be NULL)
  *   fa_out [nvox]     out, may be NULL: the FA index every voxel was fitted with
  *   chunk             voxels per block; 0 = a quarter of a plan's share, in multiples of 4 096, at most 262 144
@@ -200,9 +205,13 @@ int met2_plan_finish(met2_plan *plan, void *stream);
  * ALL plans' streams have drained -- nothing writes to the caller's arrays after the return.  The block buffers (two slots of
  * chunk x ~8 (2 n_te + n_t2 + 10) bytes on the device, the same pinned when a pageable array takes part), three streams and six
  * events stay with each plan until met2_plan_destroy. */
-int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
-                  int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol, double *sig,
-                  double *reg, double *lam, double *maps, int32_t *status, double *fa_out, int64_t chunk, double *plan_ms);
+int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
+                  int64_t voxel_stride, int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol,
+                  double *sig, double *reg, double *lam, double *maps, int32_t *status, double *fa_out, int64_t chunk, double *plan_ms);
+/* For estimate_fa = 2: `plan_lr` holds the coarse-grid dictionary (motor:237-238: 15 flip angles from 90 to 180 degrees), same n_te x n_t2
+ * and device as `plan`; alpha_lr [n_lr = its flip angles] and alpha_hr [n_hr = the plan's flip angles] are the two grids in degrees (HOST
+ * arrays, copied).  plan_lr must outlive the attachment; plan_lr = NULL detaches. */
+int met2_plan_attach_fa_spline(met2_plan *plan, met2_plan *plan_lr, int32_t n_lr, const double *alpha_lr, int32_t n_hr, const double *alpha_hr);
 
 /* Test/diagnostic entry: `method` = 10 + MET2_X2 / MET2_GCV / MET2_BAYESREG passed to met2_fit
  * evaluates that method's lambda-selection objective (algorithms.py:226-233, :285-296,

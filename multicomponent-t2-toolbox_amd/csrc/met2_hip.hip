@@ -1276,6 +1276,13 @@ extern "C" int met2_nesma(int32_t device, int32_t nx, int32_t ny, int32_t nz, in
 
 struct SplineTables { int device = -1; double *d = nullptr; size_t cap = 0; std::vector<double> last; };
 static thread_local SplineTables g_spline_tables;
+// for host threads that end (met2_fit_host's per-plan threads): frees the calling thread's tables
+namespace met2 { __attribute__((visibility("hidden"))) void spline_tables_release()
+{
+    SplineTables &T = g_spline_tables;
+    if (T.d) { DevGuard g(T.device); (void)hipDeviceSynchronize(); (void)hipFree(T.d); }
+    T.d = nullptr; T.cap = 0; T.device = -1; T.last.clear();
+} }
 
 extern "C" int met2_fa_spline_select_strided(int32_t device, int64_t nvox, int32_t n_lr, const double *alpha_lr, const double *resid,
                                              int32_t n_hr, const double *alpha_hr, int32_t n_te, const double *data, int64_t voxel_stride,

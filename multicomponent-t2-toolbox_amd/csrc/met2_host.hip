@@ -27,6 +27,8 @@
 #include "../../include/met2_hip.h"
 #include "abi_common.hpp"
 
+namespace met2 { __attribute__((visibility("hidden"))) void spline_tables_release(); }
+
 namespace {
 
 // what one plan keeps between calls for this entry: streams, events, two block slots on the device and (when some host array is pageable)
@@ -40,7 +42,12 @@ struct Work {
     int device = -1;
     int64_t cap = 0;          // voxels per slot
     int nte = 0, nt2 = 0;
+    int nlr = 0;              // the slots hold a [cap][nlr] residual table (spline FA method)
+    bool fa_in = false;       // ... and a second input block (the volume the FA step sees)
     bool pinned = false;
+    // the spline FA method's configuration (met2_plan_attach_fa_spline)
+    met2_plan *plan_lr = nullptr;
+    std::vector<double> alpha_lr, alpha_hr;
     hipStream_t s_in = nullptr, s_fit = nullptr, s_out = nullptr;
     Slot slot[2];
 };
@@ -50,8 +57,8 @@ std::map<met2_plan *, Work *> g_work;
 
 // slab layout of a slot with capacity `cap` voxels (byte offsets, every array 16-byte aligned)
 struct Layout {
-    size_t in, fa, fsol, sig, reg, lam, maps, status, mk, total;
-    Layout(int64_t cap, int nte, int nt2)
+    size_t in, fa, fsol, sig, reg, lam, maps, status, mk, in_fa, resid, total;
+    Layout(int64_t cap, int nte, int nt2, int nlr, bool fa_in)
     {
         size_t o = 0;
         auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
@@ -64,6 +71,8 @@ struct Layout {
         maps = take(sizeof(double) * (size_t)cap * 6);
         status = take(sizeof(int32_t) * (size_t)cap);
         mk = take((size_t)cap);
+        in_fa = take(fa_in ? sizeof(double) * (size_t)cap * nte : 0);
+        resid = take(sizeof(double) * (size_t)cap * nlr);
         total = o;
     }
 };
@@ -114,12 +123,12 @@ void host_copy(void *dst, const void *src, size_t bytes)
 
 struct Job {
     met2_plan *const *plans; int n_plans; int method; int64_t nvox;
-    const double *data; int64_t vs, es;
+    const double *data; const double *fa_data; int64_t vs, es;
     const double *fa_index; const uint8_t *mask; int estimate_fa;
     double *fsol, *sig, *reg, *lam, *maps; int32_t *status; double *fa_out;
     int64_t chunk; int nte, nt2; bool split;
     // which host arrays the device reaches directly
-    bool pin_data, pin_fa, pin_mask, pin_fsol, pin_sig, pin_reg, pin_lam, pin_maps, pin_status, pin_fa_out;
+    bool pin_data, pin_fa_data, pin_fa, pin_mask, pin_fsol, pin_sig, pin_reg, pin_lam, pin_maps, pin_status, pin_fa_out;
     int in_case;              // 0: voxel-major rows (es == 1), 1: echo-major (vs == 1), 2: general strides (gathered on the host)
 };
 
@@ -143,19 +152,21 @@ int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, Work *
             HIPCHK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
         }
     }
-    const bool grow = w->cap < J.chunk || w->nte != J.nte || w->nt2 != J.nt2;
+    const int need_lr = J.estimate_fa == 2 ? (int)w->alpha_lr.size() : 0;
+    const bool need_fa_in = J.fa_data != nullptr;
+    const bool grow = w->cap < J.chunk || w->nte != J.nte || w->nt2 != J.nt2 || w->nlr < need_lr || (need_fa_in && !w->fa_in);
     if (grow) {
         for (Slot &s : w->slot) {
             if (s.dev) { HIPCHK(hipFree(s.dev)); s.dev = nullptr; }
             if (s.pin) { HIPCHK(hipHostFree(s.pin)); s.pin = nullptr; }
         }
         w->pinned = false;
-        w->cap = J.chunk; w->nte = J.nte; w->nt2 = J.nt2;
-        const Layout L(w->cap, w->nte, w->nt2);
+        w->cap = std::max(w->cap, J.chunk); w->nte = J.nte; w->nt2 = J.nt2; w->nlr = std::max(w->nlr, need_lr); w->fa_in = w->fa_in || need_fa_in;
+        const Layout L(w->cap, w->nte, w->nt2, w->nlr, w->fa_in);
         for (Slot &s : w->slot) HIPCHK(hipMalloc((void **)&s.dev, L.total));
     }
     if (need_pin && !w->pinned) {
-        const Layout L(w->cap, w->nte, w->nt2);
+        const Layout L(w->cap, w->nte, w->nt2, w->nlr, w->fa_in);
         for (Slot &s : w->slot) HIPCHK(hipHostMalloc((void **)&s.pin, L.total, hipHostMallocDefault));
         w->pinned = true;
     }
@@ -183,43 +194,52 @@ int pipeline(const Job &J, int t, Work *w)
             if (e) { seg.front() = {first.first + e, first.second - e}; seg.insert(seg.begin(), {first.first, e}); } }
     }
     const int64_t mine = (int64_t)seg.size();
-    const Layout L(w->cap, nte, nt2);
+    const Layout L(w->cap, nte, nt2, w->nlr, w->fa_in);
     auto lo_of = [&](int64_t c) { return seg[(size_t)c].first; };
     auto n_of = [&](int64_t c) { return seg[(size_t)c].second; };
     const bool stage_in = !J.pin_data || J.in_case == 2;
     // the block on the device: voxel-major [n][nte] (cases 0 and 2) or echo-major [nte][n] (case 1); read in place either way
     const bool dev_echo_major = J.in_case == 1;
 
+    // one input block (the volume, or the volume the FA step sees): host -> the slot's region at `off`, in the layout the kernels read
+    auto put_block = [&](Slot &S, size_t off, const double *src, bool stage, int64_t lo, int64_t n) -> int {
+        double *d_in = (double *)(S.dev + off);
+        if (stage) {
+            double *h = (double *)(S.pin + off);
+            if (J.in_case == 0) {
+                if (J.vs == nte) host_copy(h, src + lo * J.vs, sizeof(double) * (size_t)n * nte);
+                else for (int64_t v = 0; v < n; ++v) memcpy(h + v * nte, src + (lo + v) * J.vs, sizeof(double) * nte);
+            } else if (J.in_case == 1) {
+                for (int e = 0; e < nte; ++e) memcpy(h + (size_t)e * n, src + e * J.es + lo, sizeof(double) * (size_t)n);
+            } else {
+                for (int64_t v = 0; v < n; ++v)
+                    for (int e = 0; e < nte; ++e) h[v * nte + e] = src[(lo + v) * J.vs + e * J.es];
+            }
+            HIPCHK(hipMemcpyAsync(d_in, h, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
+        } else if (J.in_case == 0) {
+            if (J.vs == nte) HIPCHK(hipMemcpyAsync(d_in, src + lo * J.vs, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
+            else HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * nte, src + lo * J.vs, sizeof(double) * J.vs, sizeof(double) * nte, (size_t)n,
+                                         hipMemcpyHostToDevice, w->s_in));
+        } else {
+            HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * (size_t)n, src + lo, sizeof(double) * J.es, sizeof(double) * (size_t)n, (size_t)nte,
+                                    hipMemcpyHostToDevice, w->s_in));
+        }
+        return MET2_OK;
+    };
+    const bool stage_fa_in = J.fa_data && (!J.pin_fa_data || J.in_case == 2);
+
     auto upload = [&](int64_t c) -> int {
         Slot &S = w->slot[c & 1];
         const int64_t lo = lo_of(c), n = n_of(c);
-        double *d_in = (double *)(S.dev + L.in);
-        if (stage_in || (J.fa_index && !J.pin_fa) || (J.mask && !J.pin_mask))
+        if (stage_in || stage_fa_in || (J.fa_index && !J.pin_fa) || (J.mask && !J.pin_mask))
             if (c >= 2) HIPCHK(hipEventSynchronize(S.ev_in));        // the H2D of block c - 2 has left this pinned slot
         if (c >= 2) {                                                 // the device slot is free once block c - 2 has been fitted and its
             HIPCHK(hipStreamWaitEvent(w->s_in, S.ev_fit, 0));         // outputs (the FA indices live in it) copied out: waited for on the
             HIPCHK(hipStreamWaitEvent(w->s_in, S.ev_out, 0));         // GPU, not by this thread
         }
-        if (stage_in) {
-            double *h = (double *)(S.pin + L.in);
-            if (J.in_case == 0) {
-                if (J.vs == nte) host_copy(h, J.data + lo * J.vs, sizeof(double) * (size_t)n * nte);
-                else for (int64_t v = 0; v < n; ++v) memcpy(h + v * nte, J.data + (lo + v) * J.vs, sizeof(double) * nte);
-            } else if (J.in_case == 1) {
-                for (int e = 0; e < nte; ++e) memcpy(h + (size_t)e * n, J.data + e * J.es + lo, sizeof(double) * (size_t)n);
-            } else {
-                for (int64_t v = 0; v < n; ++v)
-                    for (int e = 0; e < nte; ++e) h[v * nte + e] = J.data[(lo + v) * J.vs + e * J.es];
-            }
-            HIPCHK(hipMemcpyAsync(d_in, h, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
-        } else if (J.in_case == 0) {
-            if (J.vs == nte) HIPCHK(hipMemcpyAsync(d_in, J.data + lo * J.vs, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
-            else HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * nte, J.data + lo * J.vs, sizeof(double) * J.vs, sizeof(double) * nte, (size_t)n,
-                                         hipMemcpyHostToDevice, w->s_in));
-        } else {
-            HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * (size_t)n, J.data + lo, sizeof(double) * J.es, sizeof(double) * (size_t)n, (size_t)nte,
-                                    hipMemcpyHostToDevice, w->s_in));
-        }
+        int rc_ = put_block(S, L.in, J.data, stage_in, lo, n);
+        if (rc_) return rc_;
+        if (J.fa_data && (rc_ = put_block(S, L.in_fa, J.fa_data, stage_fa_in, lo, n))) return rc_;
         if (J.fa_index) {
             const double *src = J.fa_index + lo;
             if (!J.pin_fa) { memcpy(S.pin + L.fa, src, sizeof(double) * (size_t)n); src = (const double *)(S.pin + L.fa); }
@@ -266,8 +286,17 @@ int pipeline(const Job &J, int t, Work *w)
         const int64_t dvs = dev_echo_major ? 1 : nte, des = dev_echo_major ? n : 1;
         const uint8_t *d_mk = J.mask ? (const uint8_t *)(S.dev + L.mk) : nullptr;
         double *d_fa = (J.fa_index || J.estimate_fa) ? (double *)(S.dev + L.fa) : nullptr;
-        if (J.estimate_fa) {
-            rc = met2_fa_bruteforce_strided(plan, n, d_in, dvs, des, d_mk, d_fa, nullptr, nullptr, w->s_fit);
+        const double *d_fa_in = J.fa_data ? (const double *)(S.dev + L.in_fa) : d_in;      // what the FA step sees (motor:337-343)
+        if (J.estimate_fa == 1) {
+            rc = met2_fa_bruteforce_strided(plan, n, d_fa_in, dvs, des, d_mk, d_fa, nullptr, nullptr, w->s_fit);
+            if (rc) return rc;
+        } else if (J.estimate_fa == 2) {
+            // fa_estimation.py:35-70: plain-NNLS residuals on the coarse grid, cubic spline through them, its bounded minimum snapped to the fine grid
+            double *d_res = (double *)(S.dev + L.resid);
+            rc = met2_fa_bruteforce_strided(w->plan_lr, n, d_fa_in, dvs, des, d_mk, d_fa, nullptr, d_res, w->s_fit);
+            if (rc) return rc;
+            rc = met2_fa_spline_select_strided(w->device, n, (int32_t)w->alpha_lr.size(), w->alpha_lr.data(), d_res, (int32_t)w->alpha_hr.size(),
+                                               w->alpha_hr.data(), nte, d_fa_in, dvs, des, d_mk, d_fa, nullptr, w->s_fit);
             if (rc) return rc;
         }
         rc = met2_fit_enqueue_strided(plan, J.method, n, d_in, dvs, des, d_fa, d_mk, (double *)(S.dev + L.fsol),
@@ -310,7 +339,7 @@ int pipeline(const Job &J, int t, Work *w)
 
 struct Outcome { int rc = MET2_OK; std::string msg; double ms = 0.0; };
 
-void run_plan(const Job &J, int t, bool need_pin, Outcome *out)
+void run_plan(const Job &J, int t, bool need_pin, bool spawned, Outcome *out)
 {
     const auto t0 = std::chrono::steady_clock::now();
     met2_options opt;
@@ -330,11 +359,47 @@ void run_plan(const Job &J, int t, bool need_pin, Outcome *out)
             out->msg = msg;
         }
     } else out->msg = met2_last_error();
+    if (spawned && J.estimate_fa == 2) met2::spline_tables_release();     // the spline step's per-thread device tables die with this thread
     out->rc = rc;
     out->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 }  // namespace
+
+extern "C" int met2_plan_attach_fa_spline(met2_plan *plan, met2_plan *plan_lr, int32_t n_lr, const double *alpha_lr, int32_t n_hr, const double *alpha_hr)
+{
+    if (!plan) return fail(MET2_E_INVALID, "NULL plan");
+    Work *w;
+    {
+        std::lock_guard<std::mutex> lock(g_work_mutex);
+        Work *&slot = g_work[plan];
+        if (!slot) {
+            met2_options opt;
+            const int rc = met2_plan_get_options(plan, &opt);
+            if (rc) { g_work.erase(plan); return rc; }
+            slot = new Work(); slot->device = opt.device;
+        }
+        w = slot;
+    }
+    if (!plan_lr) { w->plan_lr = nullptr; w->alpha_lr.clear(); w->alpha_hr.clear(); return MET2_OK; }     // detach
+    if (plan_lr == plan) return fail(MET2_E_INVALID, "the coarse plan must be another plan");
+    if (!alpha_lr || !alpha_hr) return fail(MET2_E_INVALID, "NULL argument");
+    int a = 0, b = 0, c = 0, a2 = 0, b2 = 0, c2 = 0;
+    met2_options o1, o2;
+    int rc = met2_plan_get_shape(plan, &a, &b, &c);
+    if (!rc) rc = met2_plan_get_shape(plan_lr, &a2, &b2, &c2);
+    if (!rc) rc = met2_plan_get_options(plan, &o1);
+    if (!rc) rc = met2_plan_get_options(plan_lr, &o2);
+    if (rc) return rc;
+    if (a2 != a || b2 != b || o1.device != o2.device) return fail(MET2_E_INVALID, "the coarse plan must have the plan's n_te x n_t2 and live on its device");
+    if (n_lr != c2 || n_hr != c) return fail(MET2_E_INVALID, "n_lr / n_hr must be the flip-angle counts of the coarse plan and of the plan");
+    if (n_lr < 4 || n_lr > 32) return fail(MET2_E_UNSUPPORTED, "coarse FA grid must have 4..32 points");
+    for (int i = 1; i < n_lr; ++i) if (!(alpha_lr[i] > alpha_lr[i - 1])) return fail(MET2_E_INVALID, "coarse FA grid must increase");
+    w->plan_lr = plan_lr;
+    w->alpha_lr.assign(alpha_lr, alpha_lr + n_lr);
+    w->alpha_hr.assign(alpha_hr, alpha_hr + n_hr);
+    return MET2_OK;
+}
 
 namespace met2 {
 // called by met2_plan_destroy: the block buffers, streams and events this entry keeps with a plan
@@ -350,8 +415,8 @@ __attribute__((visibility("hidden"))) void host_release(met2_plan *plan)
 }
 }  // namespace met2
 
-extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, int64_t voxel_stride,
-                             int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol, double *sig,
+extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
+                             int64_t voxel_stride, int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol, double *sig,
                              double *reg, double *lam, double *maps, int32_t *status, double *fa_out, int64_t chunk, double *plan_ms)
 {
     if (!plans || n_plans < 1 || n_plans > 64) return fail(MET2_E_INVALID, "met2_fit_host: 1 to 64 plans");
@@ -370,8 +435,17 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     if (nvox < 0) return fail(MET2_E_INVALID, "nvox out of range");
     if (!data || !fsol || !reg) return fail(MET2_E_INVALID, "NULL argument");
     if (voxel_stride <= 0 || echo_stride <= 0) return fail(MET2_E_INVALID, "met2_fit_host: strides must be positive");
-    if (estimate_fa != 0 && estimate_fa != 1) return fail(MET2_E_INVALID, "estimate_fa: 0 (given / flip angle 0) or 1 (brute force)");
+    if (estimate_fa < 0 || estimate_fa > 2) return fail(MET2_E_INVALID, "estimate_fa: 0 (given / flip angle 0), 1 (brute force) or 2 (spline)");
     if (estimate_fa && fa_index) return fail(MET2_E_INVALID, "estimate_fa together with fa_index");
+    if (fa_data && !estimate_fa) return fail(MET2_E_INVALID, "fa_data is what the FA estimation sees: it needs estimate_fa 1 or 2");
+    if (estimate_fa == 2) {
+        std::lock_guard<std::mutex> lock(g_work_mutex);
+        for (int t = 0; t < n_plans; ++t) {
+            auto it = g_work.find(plans[t]);
+            if (it == g_work.end() || !it->second->plan_lr)
+                return fail(MET2_E_STATE, "estimate_fa = 2 needs met2_plan_attach_fa_spline on every plan first");
+        }
+    }
     if (chunk < 0) return fail(MET2_E_INVALID, "chunk < 0");
     if (chunk == 0) {
         // four blocks per plan so that the copies of a plan's first and last block (the only ones not under a fit) are a quarter of its
@@ -383,23 +457,23 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     if (chunk > 0x7fffffff) return fail(MET2_E_INVALID, "chunk out of range");
 
     Job J;
-    J.plans = plans; J.n_plans = n_plans; J.method = method; J.nvox = nvox; J.data = data; J.vs = voxel_stride; J.es = echo_stride;
+    J.plans = plans; J.n_plans = n_plans; J.method = method; J.nvox = nvox; J.data = data; J.fa_data = fa_data; J.vs = voxel_stride; J.es = echo_stride;
     J.fa_index = fa_index; J.mask = mask; J.estimate_fa = estimate_fa; J.fsol = fsol; J.sig = sig; J.reg = reg; J.lam = lam; J.maps = maps;
     J.status = status; J.fa_out = fa_out; J.chunk = chunk; J.nte = nte; J.nt2 = nt2;
     J.split = getenv("MET2_HOST_NOSPLIT") == nullptr;            // test / A-B switch: whole blocks only
     J.in_case = echo_stride == 1 ? 0 : (voxel_stride == 1 ? 1 : 2);
     if (J.in_case == 0 && voxel_stride < nte) return fail(MET2_E_INVALID, "met2_fit_host: voxel_stride < n_te with echo_stride 1 (overlapping voxels)");
-    J.pin_data = is_pinned(data); J.pin_fa = is_pinned(fa_index); J.pin_mask = is_pinned(mask); J.pin_fsol = is_pinned(fsol);
+    J.pin_data = is_pinned(data); J.pin_fa_data = is_pinned(fa_data); J.pin_fa = is_pinned(fa_index); J.pin_mask = is_pinned(mask); J.pin_fsol = is_pinned(fsol);
     J.pin_sig = is_pinned(sig); J.pin_reg = is_pinned(reg); J.pin_lam = is_pinned(lam); J.pin_maps = is_pinned(maps);
     J.pin_status = is_pinned(status); J.pin_fa_out = is_pinned(fa_out);
-    const bool need_pin = !(J.pin_data && J.in_case != 2 && J.pin_fa && J.pin_mask && J.pin_fsol && J.pin_sig && J.pin_reg && J.pin_lam && J.pin_maps &&
+    const bool need_pin = !(J.pin_data && J.pin_fa_data && J.in_case != 2 && J.pin_fa && J.pin_mask && J.pin_fsol && J.pin_sig && J.pin_reg && J.pin_lam && J.pin_maps &&
                             J.pin_status && J.pin_fa_out);
 
     std::vector<Outcome> res(n_plans);
-    if (n_plans == 1) run_plan(J, 0, need_pin, &res[0]);
+    if (n_plans == 1) run_plan(J, 0, need_pin, false, &res[0]);
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < n_plans; ++t) th.emplace_back(run_plan, std::cref(J), t, need_pin, &res[t]);
+        for (int t = 0; t < n_plans; ++t) th.emplace_back(run_plan, std::cref(J), t, need_pin, true, &res[t]);
         for (auto &x : th) x.join();
     }
     if (plan_ms) for (int t = 0; t < n_plans; ++t) plan_ms[t] = res[t].ms;

@@ -18,12 +18,34 @@ def _p(a):
     return _vp(a.ctypes.data) if a is not None else _vp(0)
 
 
+FA_MODES = {False: 0, None: 0, 0: 0, True: 1, 1: 1, "brute-force": 1, 2: 2, "spline": 2}
+
+
+def attach_fa_spline(plans, plans_lr, alpha_lr, alpha_hr):
+    """met2_plan_attach_fa_spline on every plan: plans_lr[i] holds the coarse-grid dictionary (motor:237-238) on plans[i]'s device; the coarse
+    plans must stay alive while attached (plans_lr=None detaches)."""
+    plans = list(plans) if isinstance(plans, (list, tuple)) else [plans]
+    if plans_lr is None:
+        for p in plans:
+            check(lib().met2_plan_attach_fa_spline(p._h, None, 0, None, 0, None))
+        return
+    plans_lr = list(plans_lr) if isinstance(plans_lr, (list, tuple)) else [plans_lr]
+    if len(plans_lr) != len(plans):
+        raise ValueError("one coarse plan per plan")
+    al = np.ascontiguousarray(alpha_lr, dtype=np.float64); ah = np.ascontiguousarray(alpha_hr, dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    for p, q in zip(plans, plans_lr):
+        check(lib().met2_plan_attach_fa_spline(p._h, q._h, al.shape[0], al.ctypes.data_as(dp), ah.shape[0], ah.ctypes.data_as(dp)))
+
+
 def fit_host(plans, method, data, fa_index=None, mask=None, estimate_fa=False, chunk=0, want_sig=True, want_maps=True, want_status=True,
-             want_lambda=False, out=None):
+             want_lambda=False, out=None, fa_data=None):
     """plans: a Met2Plan or a sequence of them (same shape, configured alike; one per device for a multi-GPU run).
     data: float64 numpy array [..., n_te] -- a voxel list or a volume, C-ordered or the Fortran-ordered array nibabel delivers (read as
     it lies); any other layout is gathered inside the library.  fa_index / mask: per voxel, in the memory order of `data`'s voxels.
-    estimate_fa=True: brute-force FA search over the plans' FA axis per block (fa_estimation.py:74-111).
+    estimate_fa=True / 'brute-force': brute-force FA search over the plans' FA axis per block (fa_estimation.py:74-111); 'spline': the spline
+    method on the coarse plans attached with attach_fa_spline (fa_estimation.py:35-70).  fa_data: the same voxels as the FA step shall see them
+    (the smoothed volume of motor:337-343), same shape and memory layout as `data`.
     Returns numpy arrays flat in the memory order of the voxels: fsol [nvox, n_t2], sig [nvox, n_te], reg [nvox], maps [6, nvox],
     status [nvox] int32, lam [nvox], fa_index [nvox] and plan_ms (wall ms of every plan's thread).  `out`: a dict returned earlier,
     whose arrays are written again."""
@@ -47,6 +69,17 @@ def fit_host(plans, method, data, fa_index=None, mask=None, estimate_fa=False, c
         data = np.ascontiguousarray(data)
         vs, es = nte, 1
     order = "F" if (es != 1 and data.ndim > 2) else "C"
+    if estimate_fa not in FA_MODES:
+        raise ValueError("estimate_fa: False, True / 'brute-force' or 'spline'")
+    if fa_data is not None:
+        fa_data = np.asarray(fa_data)
+        if fa_data.dtype != np.float64 or fa_data.shape != data.shape or fa_data.strides != data.strides:
+            fa_data = np.asarray(fa_data, dtype=np.float64)
+            if fa_data.shape != data.shape:
+                raise ValueError("fa_data must have the shape of data")
+            lay = np.empty_like(data)            # same memory layout as data
+            lay[...] = fa_data
+            fa_data = lay
 
     def per_voxel(a, dt, what):
         if a is None:
@@ -77,7 +110,7 @@ def fit_host(plans, method, data, fa_index=None, mask=None, estimate_fa=False, c
            "status": buf("status", (nvox,), np.int32, want=want_status), "fa_index": buf("fa_index", (nvox,))}
     handles = (_vp * len(plans))(*[p._h for p in plans])
     ms = np.zeros(len(plans))
-    check(lib().met2_fit_host(handles, len(plans), METHODS[method], nvox, _p(data), vs, es, _p(fa), _p(mk), 1 if estimate_fa else 0,
+    check(lib().met2_fit_host(handles, len(plans), METHODS[method], nvox, _p(data), _p(fa_data), vs, es, _p(fa), _p(mk), FA_MODES[estimate_fa],
                               _p(res["fsol"]), _p(res["sig"]), _p(res["reg"]), _p(res["lam"]), _p(res["maps"]), _p(res["status"]),
                               _p(res["fa_index"]), int(chunk), ms.ctypes.data_as(C.POINTER(C.c_double))))
     res["plan_ms"] = ms

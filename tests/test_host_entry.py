@@ -219,9 +219,9 @@ def test_host_entry_through_raw_ctypes_against_the_oracle(pkg, oracle):
     data, _, _ = synth.make_voxels(nvox, nte=nte, seed=7, device="cpu")
     data = data.numpy()
     fsol = np.empty((nvox, nt2)); reg = np.empty(nvox); maps = np.empty((6, nvox)); ms = np.zeros(2)
-    L.met2_fit_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + \
+    L.met2_fit_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + \
         [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]
-    rc = L.met2_fit_host(plans, 2, 2, nvox, data.ctypes.data, nte, 1, None, None, 0, fsol.ctypes.data, None, reg.ctypes.data, None,
+    rc = L.met2_fit_host(plans, 2, 2, nvox, data.ctypes.data, None, nte, 1, None, None, 0, fsol.ctypes.data, None, reg.ctypes.data, None,
                          maps.ctypes.data, None, None, 128, ms.ctypes.data)
     assert rc == 0, L.met2_last_error()
     for i in range(2):
@@ -235,3 +235,54 @@ def test_host_entry_through_raw_ctypes_against_the_oracle(pkg, oracle):
     mwf = oracle.metrics(fs, T2s, np.ones(nvox))["MWF"]
     assert np.max(np.abs(maps[0][ok] - mwf[ok])) < 1e-5
     assert (ms > 0).all()
+
+
+@gpu
+@pytest.mark.parametrize("count", [1, 2])
+def test_spline_fa_and_a_separate_fa_volume(pkg, count):
+    """estimate_fa = 2 (fa_estimation.py:35-70 per block, coarse plans attached) and fa_data (the volume the FA step sees, motor:337-343):
+    the flip angles of Met2Plan.fa_spline over the whole list, the fits of met2_fit with them"""
+    import torch
+    host = importlib.import_module(PKG + ".host")
+    synth = importlib.import_module(PKG + ".synth")
+    lib = importlib.import_module(PKG + "._lib")
+    nte, nt2 = 32, 60
+    alpha_hr = np.linspace(90.0, 180.0, 91)
+    alpha_lr = np.linspace(90.0, 180.0, 15)                          # motor:237
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plans, coarse = [], []
+    for _ in range(count):
+        p = pkg.Met2Plan(nte, nt2, 91); p.build_dictionary_epg(T2s, T1s, 10.0, alpha_hr, 3000.0).set_penalty("L2", T2s)
+        q = pkg.Met2Plan(nte, nt2, 15); q.build_dictionary_epg(T2s, T1s, 10.0, alpha_lr, 3000.0)
+        plans.append(p); coarse.append(q)
+    nvox = 5_000
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=33, fa_values=alpha_hr[30:], device="cpu")
+    data = data.numpy()
+    rng = np.random.default_rng(1)
+    smooth = np.abs(data * (1.0 + 0.01 * rng.standard_normal(data.shape)))          # stands for the Gaussian-smoothed volume
+    mask = (np.arange(nvox) % 6 != 1).astype(np.uint8)
+    with pytest.raises(lib.Met2Error, match="attach_fa_spline"):
+        host.fit_host(plans, "X2", data, estimate_fa="spline")
+    host.attach_fa_spline(plans, coarse, alpha_lr, alpha_hr)
+    d = torch.as_tensor(data, device="cuda"); sm = torch.as_tensor(smooth, device="cuda"); m = torch.as_tensor(mask, device="cuda")
+    for fa_src, fa_np in ((d, None), (sm, smooth)):
+        fa_ref, _, _ = plans[0].fa_spline(coarse[0], alpha_lr, alpha_hr, fa_src, m, want_km=False)
+        ref = _reference_fit(plans[0], "X2", data, fa_ref.cpu().numpy(), mask)
+        r = host.fit_host(plans, "X2", data, mask=mask, estimate_fa="spline", fa_data=fa_np, chunk=1200, want_lambda=True)
+        assert np.array_equal(r["fa_index"], fa_ref.cpu().numpy())
+        _same(r, ref)
+    # brute force on the separate FA volume, Fortran-ordered pair
+    vol = np.asfortranarray(data.reshape(10, 20, 25, nte)); vol_s = np.asfortranarray(smooth.reshape(10, 20, 25, nte))
+    flat = lambda a: a.reshape(-1, nte, order="F")                                # voxels in memory order
+    fa_ref, _, _ = plans[0].fa_bruteforce(torch.as_tensor(np.ascontiguousarray(flat(vol_s)), device="cuda"))
+    ref = _reference_fit(plans[0], "X2", flat(vol), fa_ref.cpu().numpy())
+    r = host.fit_host(plans, "X2", vol, estimate_fa="brute-force", fa_data=vol_s, chunk=1200, want_lambda=True)
+    assert np.array_equal(r["fa_index"], fa_ref.cpu().numpy())
+    _same(r, ref)
+    with pytest.raises(lib.Met2Error, match="fa_data"):
+        host.fit_host(plans, "X2", data, fa_data=smooth)
+    host.attach_fa_spline(plans, None, None, None)
+    with pytest.raises(lib.Met2Error, match="attach_fa_spline"):
+        host.fit_host(plans, "X2", data, estimate_fa="spline")
+    for p in plans + coarse:
+        p.close()
