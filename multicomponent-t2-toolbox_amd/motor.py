@@ -350,7 +350,7 @@ def _estimate_fa(plan, dd_fa, mm, FA_method, fa_index, T2s, T1s, tau, TR, alpha_
 
 def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2", FA_method="brute-force", myelin_T2=40.0,
                       fa_index=None, device=0, plan=None, denoise="None", prepared=False, FA_smooth="no", distributed=False,
-                      return_prepared=False):
+                      return_prepared=False, devices=None):
     """Steps 1-4 of motor_recon_met2 (motor:293-373, 427-472) on arrays: data [nx,ny,nz,nt] (or
     [nvox, nt]), mask [nx,ny,nz].  Mirrors the driver's preparation: data *= mask (motor:180-182),
     negative values clipped to 0 (motor:279), optional NESMA / TV filter (motor:293-333, needs a 3-D volume),
@@ -362,6 +362,9 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     distributed=True (under torch.distributed.run, one rank per GPU): every rank holds the volume, runs the FA step and the
     fit on its own interleaved 4096-voxel blocks of the voxel list and the outputs meet on rank 0 in ONE gather
     (dist.fit_sharded); ranks other than 0 return None.
+    devices=[d0, d1, ...]: ONE process drives several GPUs through the C ABI's host entry (met2_fit_host: one plan and one host thread per
+    device inside the call, blocks of voxels dealt round-robin, outputs copied by every device into the same host arrays -- no
+    torch.distributed); the whole-volume filters (TV / NESMA / FA smoothing) run on devices[0] first.  Same outputs bit for bit.
     Returns a dict with the driver's ten outputs."""
     if FA_method not in ("brute-force", "spline"):
         raise ValueError("FA_method must be 'spline' or 'brute-force'")
@@ -371,6 +374,11 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     vol_shape = data.shape[:-1]
     nt = data.shape[-1]
     mask = np.asarray(mask).reshape(vol_shape)
+    if devices is not None:
+        if plan is not None or distributed:
+            raise ValueError("devices=[...] builds its own plans and does not go with distributed=True")
+        return _recon_multi_device(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, list(devices), prepared,
+                                   denoise, FA_smooth, return_prepared)
     dev = plan.device if plan is not None else torch.device("cuda", device)
     plain = denoise in ("None", None, "none") and not (FA_smooth == "yes" and fa_index is None) and not distributed and not return_prepared
     if plain and data.ndim >= 2 and (data.flags.c_contiguous or data.flags.f_contiguous):
@@ -497,6 +505,86 @@ def _recon_pipelined(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method
             plan.close()
 
 
+def _recon_multi_device(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, fa_index, devices, prepared, denoise, FA_smooth,
+                        return_prepared=False):
+    """recon_met2_arrays(devices=[...]): one process, one plan per listed device, driven by met2_fit_host (host.fit_host).  The driver's
+    preparation runs on the host for plain runs and, with a whole-volume filter (motor:293-343), on devices[0]; steps 2-4 then go through
+    the host entry, which deals blocks of the voxel list to the devices."""
+    from . import host as mhost
+    if not devices:
+        raise ValueError("devices is empty")
+    vol_shape, nt = data.shape[:-1], data.shape[-1]
+    filtered = denoise not in ("None", None, "none") or (FA_smooth == "yes" and fa_index is None)
+    fa_vol = None
+    if filtered:
+        dev0 = torch.device("cuda", devices[0])
+        dd, _ = _prepare_volume(data, mask, dev0, prepared, denoise)
+        if FA_smooth == "yes" and fa_index is None:
+            if len(vol_shape) != 3:
+                raise ValueError("FA_smooth='yes' needs data [nx,ny,nz,nt]")
+            fa_vol = gaussian_smooth(dd, 2.0).cpu().numpy()
+        vol = dd.cpu().numpy()                                   # keeps the memory order the volume came in
+        del dd
+    elif prepared:
+        vol = data
+    else:
+        vol = data * np.asarray(mask, dtype=np.float64)[..., None]      # motor:180-182
+        np.maximum(vol, 0.0, out=vol)                                    # motor:279
+        if data.flags.f_contiguous and not data.flags.c_contiguous:
+            vol = np.asfortranarray(vol)
+    if not (vol.flags.c_contiguous or vol.flags.f_contiguous):
+        vol = np.ascontiguousarray(vol)
+    order = "C" if vol.flags.c_contiguous else "F"
+    TE_array = np.asarray(TE_array, dtype=np.float64)
+    tau = float(TE_array[1] - TE_array[0])
+    Npc = 96 if reg_method == "T2SPARC" else 60
+    T2s = np.logspace(math.log10(10.0), math.log10(2000.0), num=Npc, endpoint=True, base=10.0)
+    T1s = 1000.0 * np.ones_like(T2s)
+    alpha_values = np.linspace(90.0, 180.0, 91 * 3 if FA_method == "spline" else 91)      # motor:231-244
+    plans, coarse = [], []
+    try:
+        for d in devices:
+            p = Met2Plan(nt, Npc, alpha_values.shape[0], device=d, myelin_T2=myelin_T2)
+            plans.append(p)
+            p.build_dictionary_epg(T2s, T1s, tau, alpha_values, TR)
+            p.set_penalty("InvT2" if reg_method == "T2SPARC" else reg_matrix, T2s)      # run_real_data_script.py:91-93
+        mode = False
+        if fa_index is None:
+            mode = "brute-force"
+            if FA_method == "spline":
+                alpha_lr = np.linspace(90.0, 180.0, 15)                                    # motor:237
+                for d in devices:
+                    q = Met2Plan(nt, Npc, 15, device=d)
+                    coarse.append(q)
+                    q.build_dictionary_epg(T2s, T1s, tau, alpha_lr, TR)
+                mhost.attach_fa_spline(plans, coarse, alpha_lr, alpha_values)
+                mode = "spline"
+        out = mhost.fit_host(plans, reg_method, vol, fa_index=fa_index, mask=mask > 0, estimate_fa=mode, fa_data=fa_vol, chunk=PIPELINE_CHUNK if len(devices) == 1 else 0)
+    finally:
+        for p in plans + coarse:
+            p.close()
+    rv = tuple(reversed(vol_shape))
+    nd = len(vol_shape)
+
+    def unfold(a, lead=0):                                        # flat in the volume's memory order -> the volume's logical shape
+        if order == "C":
+            return a.reshape(a.shape[:lead] + vol_shape + a.shape[lead + 1:])
+        u = a.reshape(a.shape[:lead] + rv + a.shape[lead + 1:])
+        return u.transpose(list(range(lead)) + [lead + nd - 1 - i for i in range(nd)] + list(range(lead + nd, u.ndim)))
+
+    res = {"fsol_4D": unfold(out["fsol"]), "Est_Signal": unfold(out["sig"]), "reg_param": unfold(out["reg"]), "FA_index": unfold(out["fa_index"])}
+    fa_src = vol if fa_vol is None else fa_vol
+    fitted_fa = (mask > 0) & (fa_src.sum(axis=-1) > 0)            # gate of the FA step (fa_estimation.py:45)
+    res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
+    maps = unfold(out["maps"], lead=1)
+    for i, name in enumerate(MAP_NAMES):
+        res[name] = maps[i]
+    res["T2s"] = T2s
+    if return_prepared:
+        res["data_prepared"] = vol
+    return res
+
+
 def _recon_sharded(plan, dd, dd_fa, mm, reg_method, FA_method, fa_index, T2s, T1s, tau, TR, alpha_values, device, vol_shape):
     """The multi-GPU leg of recon_met2_arrays: this rank's interleaved blocks through FA estimation + fit, one gather."""
     from . import dist as mdist
@@ -532,12 +620,12 @@ def _recon_sharded(plan, dd, dd_fa, mm, reg_method, FA_method, fa_index, T2s, T1
 
 
 def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR, reg_method, reg_matrix, denoise, FA_method,
-                     FA_smooth, myelin_T2, num_cores=-1, device=0):
+                     FA_smooth, myelin_T2, num_cores=-1, device=0, devices=None):
     """Drop-in for motor_recon_met2 (motor:165-506) with the reference's on-disk contract: NIfTI in
     (data [nx,ny,nz,nt], mask [nx,ny,nz]), ten NIfTI volumes out (MWF, IEWF, FWF, T2_M, T2_IE, TWC, FA, fsol_4D,
     Est_Signal, reg_param .nii.gz at path_to_save_data, motor:475-503).  `num_cores` is accepted and ignored (one
-    process drives the GPU).  denoise: 'None', 'NESMA' (motor:305-333) or 'TV' (motor:293-304).  Not reproduced: the
-    mean-spectrum PNG of motor:377-424."""
+    process drives the GPU; devices=[0, 1, ...]: that one process drives all the listed GPUs through met2_fit_host).  denoise: 'None',
+    'NESMA' (motor:305-333) or 'TV' (motor:293-304).  Not reproduced: the mean-spectrum PNG of motor:377-424."""
     from . import nifti
     img = nifti.load(path_to_data)
     data = img.get_fdata().astype(np.float64, copy=False)           # Fortran-ordered, like nibabel's: read in place by the solver
@@ -545,7 +633,7 @@ def motor_recon_met2(TE_array, path_to_data, path_to_mask, path_to_save_data, TR
     if data.ndim != 4 or mask.shape != data.shape[:3]:
         raise ValueError("data must be 4-D and mask must match its first three dimensions")
     res = recon_met2_arrays(data, mask, TE_array, TR, reg_method, reg_matrix, FA_method, myelin_T2, device=device, denoise=denoise,
-                            FA_smooth=FA_smooth, return_prepared=(denoise == "TV"))
+                            FA_smooth=FA_smooth, return_prepared=(denoise == "TV"), devices=devices)
     if denoise == "TV":                                             # motor:302-303
         nifti.save(nifti.NiftiImage(res.pop("data_prepared"), img.affine), path_to_save_data + "Data_denoised.nii.gz")
     for name in ("MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC", "FA", "fsol_4D", "Est_Signal", "reg_param"):

@@ -286,3 +286,40 @@ def test_spline_fa_and_a_separate_fa_volume(pkg, count):
         host.fit_host(plans, "X2", data, estimate_fa="spline")
     for p in plans + coarse:
         p.close()
+
+
+@gpu
+@pytest.mark.parametrize("order,denoise,smooth,fa_method,devices", [("C", "None", "no", "spline", [0, 0]), ("F", "None", "no", "brute-force", [0, 0, 0]),
+                                                                    ("F", "TV", "yes", "spline", [0, 0]), ("C", "NESMA", "yes", "brute-force", [0]),
+                                                                    ("C", "None", "no", "given", [0, 0])])
+def test_driver_with_a_device_list_equals_the_default_driver(pkg, order, denoise, smooth, fa_method, devices):
+    """recon_met2_arrays(devices=[...]): one process, one plan per listed device through met2_fit_host -- the ten outputs of the default
+    (torch-pipelined, one device) driver bit for bit; mask values 0 / 2, negative samples, both memory orders"""
+    motor = importlib.import_module(PKG + ".motor")
+    synth = importlib.import_module(PKG + ".synth")
+    dims = (14, 12, 13)
+    nvox = int(np.prod(dims))
+    alphas = np.linspace(90.0, 180.0, 91)
+    data, fa, _ = synth.make_voxels(nvox, nte=32, seed=91, fa_values=alphas, device="cuda")
+    vol = data.cpu().numpy().reshape(dims + (32,))
+    rng = np.random.default_rng(5)
+    vol[rng.integers(0, 14, 20), rng.integers(0, 12, 20), rng.integers(0, 13, 20), rng.integers(0, 32, 20)] *= -1.0
+    mask = np.ones(dims, dtype=np.int64); mask[::5, ::3, :] = 0; mask[1, 1, 1] = 2
+    if order == "F":
+        vol = np.asfortranarray(vol)
+    TE = 10.0 * np.arange(1, 33)
+    fa_given = fa.cpu().numpy().reshape(dims) if fa_method == "given" else None
+    method = "brute-force" if fa_method == "given" else fa_method
+    keep = motor.PIPELINE_CHUNK
+    try:
+        motor.PIPELINE_CHUNK = 700
+        ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given)
+        got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given, devices=devices)
+    finally:
+        motor.PIPELINE_CHUNK = keep
+    for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
+        assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), k
+    if denoise == "TV":                                             # the file-level driver saves the denoised volume (motor:302-303)
+        a = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
+        b = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True, devices=devices)
+        assert np.array_equal(a["data_prepared"], b["data_prepared"]) and np.array_equal(a["MWF"], b["MWF"], equal_nan=True)
