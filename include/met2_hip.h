@@ -183,13 +183,18 @@ int met2_plan_finish(met2_plan *plan, void *stream);
  *                     iteration count).  Every plan is driven by its own host thread inside the call (one plan:
  *                     the calling thread) through three streams of its device: H2D of its block c + 1 | [FA estimation and] fit of
  *                     block c | D2H of block c - 1.  There is no exchange between devices.
- *   ALL array arguments are HOST pointers; arrays in pinned memory (hipHostMalloc, hipHostRegister) are copied from / to in place,
- *   pageable ones are staged through pinned block buffers by the plan's thread while its device works:
+ *   ALL array arguments are HOST pointers (data and fa_data may ALSO be device pointers: the volume as met2_tv_chambolle / met2_nesma /
+ *   met2_smooth_separable left it -- then copied block by block device to device); arrays in pinned memory (hipHostMalloc,
+ *   hipHostRegister) are copied from / to in place, pageable ones are staged through pinned block buffers by the plan's thread while its
+ *   device works:
  *   data              echo e of voxel v at data[v * voxel_stride + e * echo_stride] (strides in doubles, > 0): [nvox][n_te] rows
  *                     (echo_stride 1) and the Fortran-ordered volume of nibabel (voxel_stride 1, echo_stride nvox) are copied as they
  *                     lie and read in place on the device; any other layout is gathered on the host
  *   fa_data           NULL, or the same voxel list (same layout and strides) as the FA estimation shall see it: the Gaussian-smoothed
  *                     volume of motor:337-343 (FA_smooth='yes', the CLI default); needs estimate_fa != 0
+ *   mask_values       NULL, or [nvox] float64: the driver's preparation on the device -- every echo of voxel v is multiplied by
+ *                     mask_values[v] and negative values are clipped to 0 (motor:180-182, :279) before anything else sees the block
+ *                     (fa_data, when given, is taken as prepared already)
  *   fa_index, mask    [nvox] float64 / uint8 as for met2_fit, NULL = flip angle 0 / all ones
  *   estimate_fa       0: the flip angles are given (fa_index, or angle 0);  fa_index must be NULL otherwise;
  *                     1: brute-force search over the plans' FA axis on every block (met2_fa_bruteforce, fa_estimation.py:74-111);
@@ -198,20 +203,26 @@ int met2_plan_finish(met2_plan *plan, void *stream);
  *                        plans' own FA axis (met2_fa_bruteforce on the coarse plan + met2_fa_spline_select, per block)
  *   fsol [nvox][n_t2], sig [nvox][n_te], reg, lam [nvox], maps [6][nvox], status [nvox]   as for met2_fit (sig, lam, maps, status may be NULL)
  *   fa_out [nvox]     out, may be NULL: the FA index every voxel was fitted with
+ *   fa_gate [nvox]    out, may be NULL: 1.0 where the FA step's gate holds (fa_estimation.py:45: mask and a positive echo sum of what
+ *                     the FA step sees), else 0.0 -- the driver reports a flip angle only there (motor:366-370)
  *   chunk             voxels per block; 0 = a quarter of a plan's share, in multiples of 4 096, at most 262 144
  *   plan_ms [n_plans] out, may be NULL: wall-clock ms every plan's thread spent in the call
  * Blocking.  Every voxel is solved on its own, so the outputs are bit for bit those of one met2_fit over the whole list, whatever
  * n_plans, chunk and the devices.  Returns the first failing plan's code (an FA index outside the dictionary: MET2_E_INVALID) after
  * ALL plans' streams have drained -- nothing writes to the caller's arrays after the return.  The block buffers (two slots of
  * chunk x ~8 (2 n_te + n_t2 + 10) bytes on the device, the same pinned when a pageable array takes part), three streams and six
- * events stay with each plan until met2_plan_destroy. */
+ * events stay with each plan until met2_plan_destroy (and then wait for the next plan on that device: met2_host_trim). */
 int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
-                  int64_t voxel_stride, int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol,
-                  double *sig, double *reg, double *lam, double *maps, int32_t *status, double *fa_out, int64_t chunk, double *plan_ms);
+                  int64_t voxel_stride, int64_t echo_stride, const double *mask_values, const double *fa_index, const uint8_t *mask,
+                  int32_t estimate_fa, double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, double *fa_out,
+                  double *fa_gate, int64_t chunk, double *plan_ms);
 /* For estimate_fa = 2: `plan_lr` holds the coarse-grid dictionary (motor:237-238: 15 flip angles from 90 to 180 degrees), same n_te x n_t2
  * and device as `plan`; alpha_lr [n_lr = its flip angles] and alpha_hr [n_hr = the plan's flip angles] are the two grids in degrees (HOST
  * arrays, copied).  plan_lr must outlive the attachment; plan_lr = NULL detaches. */
 int met2_plan_attach_fa_spline(met2_plan *plan, met2_plan *plan_lr, int32_t n_lr, const double *alpha_lr, int32_t n_hr, const double *alpha_hr);
+/* met2_plan_destroy hands a plan's block buffers of met2_fit_host to the next plan created on the same device (at most two sets per device
+ * wait; a driver that builds its plans per call then allocates and pins nothing per call); this frees the waiting ones. */
+int met2_host_trim(void);
 
 /* Test/diagnostic entry: `method` = 10 + MET2_X2 / MET2_GCV / MET2_BAYESREG passed to met2_fit
  * evaluates that method's lambda-selection objective (algorithms.py:226-233, :285-296,

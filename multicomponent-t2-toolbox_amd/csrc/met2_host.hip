@@ -31,6 +31,28 @@ namespace met2 { __attribute__((visibility("hidden"))) void spline_tables_releas
 
 namespace {
 
+// motor:180-182 and :279 on a block: every echo of voxel v times mask_values[v], negative values clipped to 0 (in place).
+// The block is [n][nte] (vs = nte, es = 1) or [nte][n] (vs = 1, es = n): element i belongs to voxel i / nte or i % n.
+__global__ void host_prepare_kernel(double *d, const double *mv, int64_t n, int nte, int echo_major)
+{
+    const int64_t total = n * nte;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = echo_major ? i % n : i / nte;
+        const double x = d[i] * mv[v];
+        d[i] = x > 0.0 ? x : (x != x ? x : 0.0);                       // np.maximum-style clip that keeps nan (the fit flags it)
+    }
+}
+
+// the gate of the FA step (fa_estimation.py:45): mask and a positive echo sum, as 1.0 / 0.0 per voxel
+__global__ void host_gate_kernel(const double *d, const uint8_t *mk, int64_t n, int nte, int64_t vs, int64_t es, double *gate)
+{
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+        double t = 0.0;
+        for (int e = 0; e < nte; ++e) t += d[v * vs + e * es];
+        gate[v] = (t > 0.0 && (!mk || mk[v])) ? 1.0 : 0.0;
+    }
+}
+
 // what one plan keeps between calls for this entry: streams, events, two block slots on the device and (when some host array is pageable)
 // two pinned staging slots.  Grown on demand, freed by met2_plan_destroy (met2::host_release).
 struct Slot {
@@ -44,35 +66,52 @@ struct Work {
     int nte = 0, nt2 = 0;
     int nlr = 0;              // the slots hold a [cap][nlr] residual table (spline FA method)
     bool fa_in = false;       // ... and a second input block (the volume the FA step sees)
-    bool pinned = false;
-    // the spline FA method's configuration (met2_plan_attach_fa_spline)
-    met2_plan *plan_lr = nullptr;
-    std::vector<double> alpha_lr, alpha_hr;
+    size_t pin_bytes = 0;     // size of each slot's pinned slab
     hipStream_t s_in = nullptr, s_fit = nullptr, s_out = nullptr;
     Slot slot[2];
 };
 
+// the spline FA method's configuration of a plan (met2_plan_attach_fa_spline)
+struct Attach {
+    met2_plan *plan_lr = nullptr;
+    std::vector<double> alpha_lr, alpha_hr;
+};
+
 std::mutex g_work_mutex;
 std::map<met2_plan *, Work *> g_work;
+std::map<met2_plan *, Attach> g_attach;
+// Buffers of destroyed plans wait here for the next plan on their device: a driver that builds its plans per call (recon_met2_arrays does)
+// would otherwise allocate 0.6 GB of device memory and pin as much host memory per call -- tens of ms.  At most two per device;
+// met2_host_trim() frees them.
+std::vector<Work *> g_pool;
 
-// slab layout of a slot with capacity `cap` voxels (byte offsets, every array 16-byte aligned)
+// which arrays a slab holds
+struct Regions {
+    bool in = true, fa = true, fsol = true, sig = true, reg = true, lam = true, maps = true, status = true, mk = true, mv = true, gate = true, in_fa = false;
+    int nlr = 0;
+};
+
+// slab layout of a slot with capacity `cap` voxels (byte offsets, every array 16-byte aligned).  The device slab holds every array; the
+// pinned slab only those the caller keeps in pageable memory (a driver with pinned outputs stages 256 of 1 100 bytes per voxel).
 struct Layout {
-    size_t in, fa, fsol, sig, reg, lam, maps, status, mk, in_fa, resid, total;
-    Layout(int64_t cap, int nte, int nt2, int nlr, bool fa_in)
+    size_t in, fa, fsol, sig, reg, lam, maps, status, mk, mv, gate, in_fa, resid, total;
+    Layout(int64_t cap, int nte, int nt2, const Regions &r)
     {
         size_t o = 0;
-        auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) & ~(size_t)15; return at; };
-        in = take(sizeof(double) * (size_t)cap * nte);
-        fa = take(sizeof(double) * (size_t)cap);
-        fsol = take(sizeof(double) * (size_t)cap * nt2);
-        sig = take(sizeof(double) * (size_t)cap * nte);
-        reg = take(sizeof(double) * (size_t)cap);
-        lam = take(sizeof(double) * (size_t)cap);
-        maps = take(sizeof(double) * (size_t)cap * 6);
-        status = take(sizeof(int32_t) * (size_t)cap);
-        mk = take((size_t)cap);
-        in_fa = take(fa_in ? sizeof(double) * (size_t)cap * nte : 0);
-        resid = take(sizeof(double) * (size_t)cap * nlr);
+        auto take = [&](bool have, size_t bytes) { const size_t at = o; if (have) o += (bytes + 15) & ~(size_t)15; return at; };
+        in = take(r.in, sizeof(double) * (size_t)cap * nte);
+        fa = take(r.fa, sizeof(double) * (size_t)cap);
+        fsol = take(r.fsol, sizeof(double) * (size_t)cap * nt2);
+        sig = take(r.sig, sizeof(double) * (size_t)cap * nte);
+        reg = take(r.reg, sizeof(double) * (size_t)cap);
+        lam = take(r.lam, sizeof(double) * (size_t)cap);
+        maps = take(r.maps, sizeof(double) * (size_t)cap * 6);
+        status = take(r.status, sizeof(int32_t) * (size_t)cap);
+        mk = take(r.mk, (size_t)cap);
+        mv = take(r.mv, sizeof(double) * (size_t)cap);
+        gate = take(r.gate, sizeof(double) * (size_t)cap);
+        in_fa = take(r.in_fa, sizeof(double) * (size_t)cap * nte);
+        resid = take(r.nlr > 0, sizeof(double) * (size_t)cap * (size_t)r.nlr);
         total = o;
     }
 };
@@ -94,16 +133,19 @@ void free_work(Work *w)
     delete w;
 }
 
-// is this host pointer in memory the device can DMA from / to directly?
-bool is_pinned(const void *ptr)
+// 0: ordinary (pageable) host memory, 1: pinned host memory (the device can DMA from / to it directly), 2: device memory
+int mem_kind(const void *ptr)
 {
-    if (!ptr) return true;
+    if (!ptr) return 1;
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof(at));
     const hipError_t e = hipPointerGetAttributes(&at, ptr);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }      // ordinary (pageable) memory is unknown to the runtime
-    return at.type == hipMemoryTypeHost;
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }          // pageable memory is unknown to the runtime
+    if (at.type == hipMemoryTypeHost) return 1;
+    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeArray || at.type == hipMemoryTypeManaged) return 2;
+    return 0;
 }
+bool is_pinned(const void *ptr) { return mem_kind(ptr) == 1; }
 
 // dst <- src on the calling thread plus up to three helpers (a block of 262 144 voxels is 67 MB in and 208 MB out; one thread's
 // memcpy would stand next to a 37 ms fit)
@@ -121,24 +163,43 @@ void host_copy(void *dst, const void *src, size_t bytes)
     for (auto &h : helpers) h.join();
 }
 
+// `rows` rows of row_bytes each, pitches in bytes: the rows are dealt to the calling thread and up to three helpers when there is enough to copy
+void host_copy_rows(char *dst, size_t dst_pitch, const char *src, size_t src_pitch, size_t row_bytes, int64_t rows)
+{
+    auto run = [=](int64_t r0, int64_t r1) { for (int64_t r = r0; r < r1; ++r) memcpy(dst + r * dst_pitch, src + r * src_pitch, row_bytes); };
+    if (row_bytes * (size_t)rows < ((size_t)8 << 20) || rows < 4) { run(0, rows); return; }
+    const int parts = 4;
+    std::thread helpers[parts - 1];
+    for (int i = 1; i < parts; ++i) helpers[i - 1] = std::thread(run, rows * i / parts, rows * (i + 1) / parts);
+    run(0, rows / parts);
+    for (auto &h : helpers) h.join();
+}
+
 struct Job {
     met2_plan *const *plans; int n_plans; int method; int64_t nvox;
     const double *data; const double *fa_data; int64_t vs, es;
-    const double *fa_index; const uint8_t *mask; int estimate_fa;
-    double *fsol, *sig, *reg, *lam, *maps; int32_t *status; double *fa_out;
+    const double *fa_index; const uint8_t *mask; const double *mask_values; int estimate_fa;
+    double *fsol, *sig, *reg, *lam, *maps; int32_t *status; double *fa_out, *fa_gate;
     int64_t chunk; int nte, nt2; bool split;
     // which host arrays the device reaches directly
-    bool pin_data, pin_fa_data, pin_fa, pin_mask, pin_fsol, pin_sig, pin_reg, pin_lam, pin_maps, pin_status, pin_fa_out;
+    bool pin_data, pin_fa_data, pin_fa, pin_mask, pin_mv, pin_gate, pin_fsol, pin_sig, pin_reg, pin_lam, pin_maps, pin_status, pin_fa_out;
+    Regions stage;            // the arrays that go through the pinned slab
     int in_case;              // 0: voxel-major rows (es == 1), 1: echo-major (vs == 1), 2: general strides (gathered on the host)
 };
 
-int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, Work **out)
+int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, const Attach &at, Work **out)
 {
     Work *w;
     {
         std::lock_guard<std::mutex> lock(g_work_mutex);
         Work *&slot = g_work[plan];
-        if (!slot) { slot = new Work(); slot->device = device; }
+        if (!slot) {
+            int best = -1;
+            for (size_t i = 0; i < g_pool.size(); ++i)
+                if (g_pool[i]->device == device && (best < 0 || g_pool[i]->cap > g_pool[(size_t)best]->cap)) best = (int)i;
+            if (best >= 0) { slot = g_pool[(size_t)best]; g_pool.erase(g_pool.begin() + best); }
+            else { slot = new Work(); slot->device = device; }
+        }
         w = slot;
     }
     USE_DEVICE(device);
@@ -152,7 +213,7 @@ int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, Work *
             HIPCHK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
         }
     }
-    const int need_lr = J.estimate_fa == 2 ? (int)w->alpha_lr.size() : 0;
+    const int need_lr = J.estimate_fa == 2 ? (int)at.alpha_lr.size() : 0;
     const bool need_fa_in = J.fa_data != nullptr;
     const bool grow = w->cap < J.chunk || w->nte != J.nte || w->nt2 != J.nt2 || w->nlr < need_lr || (need_fa_in && !w->fa_in);
     if (grow) {
@@ -160,22 +221,26 @@ int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, Work *
             if (s.dev) { HIPCHK(hipFree(s.dev)); s.dev = nullptr; }
             if (s.pin) { HIPCHK(hipHostFree(s.pin)); s.pin = nullptr; }
         }
-        w->pinned = false;
+        w->pin_bytes = 0;
         w->cap = std::max(w->cap, J.chunk); w->nte = J.nte; w->nt2 = J.nt2; w->nlr = std::max(w->nlr, need_lr); w->fa_in = w->fa_in || need_fa_in;
-        const Layout L(w->cap, w->nte, w->nt2, w->nlr, w->fa_in);
+        Regions all; all.in_fa = w->fa_in; all.nlr = w->nlr;
+        const Layout L(w->cap, w->nte, w->nt2, all);
         for (Slot &s : w->slot) HIPCHK(hipMalloc((void **)&s.dev, L.total));
     }
-    if (need_pin && !w->pinned) {
-        const Layout L(w->cap, w->nte, w->nt2, w->nlr, w->fa_in);
-        for (Slot &s : w->slot) HIPCHK(hipHostMalloc((void **)&s.pin, L.total, hipHostMallocDefault));
-        w->pinned = true;
+    const size_t pin_need = need_pin ? Layout(w->cap, w->nte, w->nt2, J.stage).total : 0;
+    if (pin_need > w->pin_bytes) {
+        for (Slot &s : w->slot) {
+            if (s.pin) { HIPCHK(hipHostFree(s.pin)); s.pin = nullptr; }
+            HIPCHK(hipHostMalloc((void **)&s.pin, pin_need, hipHostMallocDefault));
+        }
+        w->pin_bytes = pin_need;
     }
     *out = w;
     return MET2_OK;
 }
 
 // one plan's share of the job: blocks t, t + n_plans, t + 2 n_plans, ...
-int pipeline(const Job &J, int t, Work *w)
+int pipeline(const Job &J, int t, Work *w, const Attach &at)
 {
     met2_plan *plan = J.plans[t];
     const int nte = J.nte, nt2 = J.nt2;
@@ -194,7 +259,9 @@ int pipeline(const Job &J, int t, Work *w)
             if (e) { seg.front() = {first.first + e, first.second - e}; seg.insert(seg.begin(), {first.first, e}); } }
     }
     const int64_t mine = (int64_t)seg.size();
-    const Layout L(w->cap, nte, nt2, w->nlr, w->fa_in);
+    Regions all_; all_.in_fa = w->fa_in; all_.nlr = w->nlr;
+    const Layout L(w->cap, nte, nt2, all_);          // device slab
+    const Layout P(w->cap, nte, nt2, J.stage);       // pinned slab
     auto lo_of = [&](int64_t c) { return seg[(size_t)c].first; };
     auto n_of = [&](int64_t c) { return seg[(size_t)c].second; };
     const bool stage_in = !J.pin_data || J.in_case == 2;
@@ -202,27 +269,28 @@ int pipeline(const Job &J, int t, Work *w)
     const bool dev_echo_major = J.in_case == 1;
 
     // one input block (the volume, or the volume the FA step sees): host -> the slot's region at `off`, in the layout the kernels read
-    auto put_block = [&](Slot &S, size_t off, const double *src, bool stage, int64_t lo, int64_t n) -> int {
+    auto put_block = [&](Slot &S, size_t off, size_t poff, const double *src, bool stage, int64_t lo, int64_t n) -> int {
         double *d_in = (double *)(S.dev + off);
         if (stage) {
-            double *h = (double *)(S.pin + off);
+            double *h = (double *)(S.pin + poff);
             if (J.in_case == 0) {
                 if (J.vs == nte) host_copy(h, src + lo * J.vs, sizeof(double) * (size_t)n * nte);
-                else for (int64_t v = 0; v < n; ++v) memcpy(h + v * nte, src + (lo + v) * J.vs, sizeof(double) * nte);
+                else host_copy_rows((char *)h, sizeof(double) * nte, (const char *)(src + lo * J.vs), sizeof(double) * (size_t)J.vs, sizeof(double) * nte, n);
             } else if (J.in_case == 1) {
-                for (int e = 0; e < nte; ++e) memcpy(h + (size_t)e * n, src + e * J.es + lo, sizeof(double) * (size_t)n);
+                host_copy_rows((char *)h, sizeof(double) * (size_t)n, (const char *)(src + lo), sizeof(double) * (size_t)J.es, sizeof(double) * (size_t)n, nte);
             } else {
                 for (int64_t v = 0; v < n; ++v)
                     for (int e = 0; e < nte; ++e) h[v * nte + e] = src[(lo + v) * J.vs + e * J.es];
             }
             HIPCHK(hipMemcpyAsync(d_in, h, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
         } else if (J.in_case == 0) {
-            if (J.vs == nte) HIPCHK(hipMemcpyAsync(d_in, src + lo * J.vs, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
+            // (hipMemcpyDefault: the source is pinned host memory or, for a volume that a filter left on a device, device memory)
+            if (J.vs == nte) HIPCHK(hipMemcpyAsync(d_in, src + lo * J.vs, sizeof(double) * (size_t)n * nte, hipMemcpyDefault, w->s_in));
             else HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * nte, src + lo * J.vs, sizeof(double) * J.vs, sizeof(double) * nte, (size_t)n,
-                                         hipMemcpyHostToDevice, w->s_in));
+                                         hipMemcpyDefault, w->s_in));
         } else {
             HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * (size_t)n, src + lo, sizeof(double) * J.es, sizeof(double) * (size_t)n, (size_t)nte,
-                                    hipMemcpyHostToDevice, w->s_in));
+                                    hipMemcpyDefault, w->s_in));
         }
         return MET2_OK;
     };
@@ -231,47 +299,53 @@ int pipeline(const Job &J, int t, Work *w)
     auto upload = [&](int64_t c) -> int {
         Slot &S = w->slot[c & 1];
         const int64_t lo = lo_of(c), n = n_of(c);
-        if (stage_in || stage_fa_in || (J.fa_index && !J.pin_fa) || (J.mask && !J.pin_mask))
+        if (stage_in || stage_fa_in || (J.fa_index && !J.pin_fa) || (J.mask && !J.pin_mask) || (J.mask_values && !J.pin_mv))
             if (c >= 2) HIPCHK(hipEventSynchronize(S.ev_in));        // the H2D of block c - 2 has left this pinned slot
         if (c >= 2) {                                                 // the device slot is free once block c - 2 has been fitted and its
             HIPCHK(hipStreamWaitEvent(w->s_in, S.ev_fit, 0));         // outputs (the FA indices live in it) copied out: waited for on the
             HIPCHK(hipStreamWaitEvent(w->s_in, S.ev_out, 0));         // GPU, not by this thread
         }
-        int rc_ = put_block(S, L.in, J.data, stage_in, lo, n);
+        int rc_ = put_block(S, L.in, P.in, J.data, stage_in, lo, n);
         if (rc_) return rc_;
-        if (J.fa_data && (rc_ = put_block(S, L.in_fa, J.fa_data, stage_fa_in, lo, n))) return rc_;
+        if (J.fa_data && (rc_ = put_block(S, L.in_fa, P.in_fa, J.fa_data, stage_fa_in, lo, n))) return rc_;
         if (J.fa_index) {
             const double *src = J.fa_index + lo;
-            if (!J.pin_fa) { memcpy(S.pin + L.fa, src, sizeof(double) * (size_t)n); src = (const double *)(S.pin + L.fa); }
+            if (!J.pin_fa) { memcpy(S.pin + P.fa, src, sizeof(double) * (size_t)n); src = (const double *)(S.pin + P.fa); }
             HIPCHK(hipMemcpyAsync(S.dev + L.fa, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, w->s_in));
         }
         if (J.mask) {
             const uint8_t *src = J.mask + lo;
-            if (!J.pin_mask) { memcpy(S.pin + L.mk, src, (size_t)n); src = (const uint8_t *)(S.pin + L.mk); }
+            if (!J.pin_mask) { memcpy(S.pin + P.mk, src, (size_t)n); src = (const uint8_t *)(S.pin + P.mk); }
             HIPCHK(hipMemcpyAsync(S.dev + L.mk, src, (size_t)n, hipMemcpyHostToDevice, w->s_in));
+        }
+        if (J.mask_values) {
+            const double *src = J.mask_values + lo;
+            if (!J.pin_mv) { memcpy(S.pin + P.mv, src, sizeof(double) * (size_t)n); src = (const double *)(S.pin + P.mv); }
+            HIPCHK(hipMemcpyAsync(S.dev + L.mv, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, w->s_in));
         }
         HIPCHK(hipEventRecord(S.ev_in, w->s_in));
         return MET2_OK;
     };
 
     // D2H of one output array of block c: straight into the caller's (pinned) array, or into the pinned slot for drain()
-    auto d2h = [&](Slot &S, size_t off, void *user, bool direct, size_t bytes) -> int {
+    auto d2h = [&](Slot &S, size_t off, size_t poff, void *user, bool direct, size_t bytes) -> int {
         if (!user) return MET2_OK;
-        HIPCHK(hipMemcpyAsync(direct ? user : (void *)(S.pin + off), S.dev + off, bytes, hipMemcpyDeviceToHost, w->s_out));
+        HIPCHK(hipMemcpyAsync(direct ? user : (void *)(S.pin + poff), S.dev + off, bytes, hipMemcpyDeviceToHost, w->s_out));
         return MET2_OK;
     };
     auto drain = [&](int64_t c) -> int {
         Slot &S = w->slot[c & 1];
         const int64_t lo = lo_of(c), n = n_of(c);
         HIPCHK(hipEventSynchronize(S.ev_out));
-        if (!J.pin_fsol) host_copy(J.fsol + lo * nt2, S.pin + L.fsol, sizeof(double) * (size_t)n * nt2);
-        if (J.sig && !J.pin_sig) host_copy(J.sig + lo * nte, S.pin + L.sig, sizeof(double) * (size_t)n * nte);
-        if (!J.pin_reg) memcpy(J.reg + lo, S.pin + L.reg, sizeof(double) * (size_t)n);
-        if (J.lam && !J.pin_lam) memcpy(J.lam + lo, S.pin + L.lam, sizeof(double) * (size_t)n);
+        if (!J.pin_fsol) host_copy(J.fsol + lo * nt2, S.pin + P.fsol, sizeof(double) * (size_t)n * nt2);
+        if (J.sig && !J.pin_sig) host_copy(J.sig + lo * nte, S.pin + P.sig, sizeof(double) * (size_t)n * nte);
+        if (!J.pin_reg) memcpy(J.reg + lo, S.pin + P.reg, sizeof(double) * (size_t)n);
+        if (J.lam && !J.pin_lam) memcpy(J.lam + lo, S.pin + P.lam, sizeof(double) * (size_t)n);
         if (J.maps && !J.pin_maps)
-            for (int i = 0; i < 6; ++i) memcpy(J.maps + (size_t)i * J.nvox + lo, S.pin + L.maps + sizeof(double) * (size_t)i * n, sizeof(double) * (size_t)n);
-        if (J.status && !J.pin_status) memcpy(J.status + lo, S.pin + L.status, sizeof(int32_t) * (size_t)n);
-        if (J.fa_out && !J.pin_fa_out && J.estimate_fa) memcpy(J.fa_out + lo, S.pin + L.fa, sizeof(double) * (size_t)n);
+            for (int i = 0; i < 6; ++i) memcpy(J.maps + (size_t)i * J.nvox + lo, S.pin + P.maps + sizeof(double) * (size_t)i * n, sizeof(double) * (size_t)n);
+        if (J.status && !J.pin_status) memcpy(J.status + lo, S.pin + P.status, sizeof(int32_t) * (size_t)n);
+        if (J.fa_out && !J.pin_fa_out && J.estimate_fa) memcpy(J.fa_out + lo, S.pin + P.fa, sizeof(double) * (size_t)n);
+        if (J.fa_gate && !J.pin_gate) memcpy(J.fa_gate + lo, S.pin + P.gate, sizeof(double) * (size_t)n);
         return MET2_OK;
     };
 
@@ -286,17 +360,29 @@ int pipeline(const Job &J, int t, Work *w)
         const int64_t dvs = dev_echo_major ? 1 : nte, des = dev_echo_major ? n : 1;
         const uint8_t *d_mk = J.mask ? (const uint8_t *)(S.dev + L.mk) : nullptr;
         double *d_fa = (J.fa_index || J.estimate_fa) ? (double *)(S.dev + L.fa) : nullptr;
+        if (J.mask_values) {
+            const int64_t total = n * nte;
+            const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 16);
+            hipLaunchKernelGGL(host_prepare_kernel, dim3(blocks), dim3(256), 0, w->s_fit, (double *)(S.dev + L.in), (const double *)(S.dev + L.mv), n, nte,
+                               dev_echo_major ? 1 : 0);
+            HIPCHK(hipGetLastError());
+        }
         const double *d_fa_in = J.fa_data ? (const double *)(S.dev + L.in_fa) : d_in;      // what the FA step sees (motor:337-343)
+        if (J.fa_gate) {
+            const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 1 << 16);
+            hipLaunchKernelGGL(host_gate_kernel, dim3(blocks), dim3(256), 0, w->s_fit, d_fa_in, d_mk, n, nte, dvs, des, (double *)(S.dev + L.gate));
+            HIPCHK(hipGetLastError());
+        }
         if (J.estimate_fa == 1) {
             rc = met2_fa_bruteforce_strided(plan, n, d_fa_in, dvs, des, d_mk, d_fa, nullptr, nullptr, w->s_fit);
             if (rc) return rc;
         } else if (J.estimate_fa == 2) {
             // fa_estimation.py:35-70: plain-NNLS residuals on the coarse grid, cubic spline through them, its bounded minimum snapped to the fine grid
             double *d_res = (double *)(S.dev + L.resid);
-            rc = met2_fa_bruteforce_strided(w->plan_lr, n, d_fa_in, dvs, des, d_mk, d_fa, nullptr, d_res, w->s_fit);
+            rc = met2_fa_bruteforce_strided(at.plan_lr, n, d_fa_in, dvs, des, d_mk, d_fa, nullptr, d_res, w->s_fit);
             if (rc) return rc;
-            rc = met2_fa_spline_select_strided(w->device, n, (int32_t)w->alpha_lr.size(), w->alpha_lr.data(), d_res, (int32_t)w->alpha_hr.size(),
-                                               w->alpha_hr.data(), nte, d_fa_in, dvs, des, d_mk, d_fa, nullptr, w->s_fit);
+            rc = met2_fa_spline_select_strided(w->device, n, (int32_t)at.alpha_lr.size(), at.alpha_lr.data(), d_res, (int32_t)at.alpha_hr.size(),
+                                               at.alpha_hr.data(), nte, d_fa_in, dvs, des, d_mk, d_fa, nullptr, w->s_fit);
             if (rc) return rc;
         }
         rc = met2_fit_enqueue_strided(plan, J.method, n, d_in, dvs, des, d_fa, d_mk, (double *)(S.dev + L.fsol),
@@ -306,21 +392,22 @@ int pipeline(const Job &J, int t, Work *w)
         if (rc) return rc;
         HIPCHK(hipEventRecord(S.ev_fit, w->s_fit));
         HIPCHK(hipStreamWaitEvent(w->s_out, S.ev_fit, 0));
-        if ((rc = d2h(S, L.fsol, J.fsol + lo * nt2, J.pin_fsol, sizeof(double) * (size_t)n * nt2))) return rc;
-        if ((rc = d2h(S, L.sig, J.sig ? J.sig + lo * nte : nullptr, J.pin_sig, sizeof(double) * (size_t)n * nte))) return rc;
-        if ((rc = d2h(S, L.reg, J.reg + lo, J.pin_reg, sizeof(double) * (size_t)n))) return rc;
-        if ((rc = d2h(S, L.lam, J.lam ? J.lam + lo : nullptr, J.pin_lam, sizeof(double) * (size_t)n))) return rc;
+        if ((rc = d2h(S, L.fsol, P.fsol, J.fsol + lo * nt2, J.pin_fsol, sizeof(double) * (size_t)n * nt2))) return rc;
+        if ((rc = d2h(S, L.sig, P.sig, J.sig ? J.sig + lo * nte : nullptr, J.pin_sig, sizeof(double) * (size_t)n * nte))) return rc;
+        if ((rc = d2h(S, L.reg, P.reg, J.reg + lo, J.pin_reg, sizeof(double) * (size_t)n))) return rc;
+        if ((rc = d2h(S, L.lam, P.lam, J.lam ? J.lam + lo : nullptr, J.pin_lam, sizeof(double) * (size_t)n))) return rc;
         if (J.maps) {
             if (J.pin_maps) {
                 for (int i = 0; i < 6; ++i)
                     HIPCHK(hipMemcpyAsync(J.maps + (size_t)i * J.nvox + lo, S.dev + L.maps + sizeof(double) * (size_t)i * n, sizeof(double) * (size_t)n,
                                           hipMemcpyDeviceToHost, w->s_out));
-            } else if ((rc = d2h(S, L.maps, J.maps, false, sizeof(double) * (size_t)n * 6))) return rc;
+            } else if ((rc = d2h(S, L.maps, P.maps, J.maps, false, sizeof(double) * (size_t)n * 6))) return rc;
         }
-        if ((rc = d2h(S, L.status, J.status ? J.status + lo : nullptr, J.pin_status, sizeof(int32_t) * (size_t)n))) return rc;
+        if ((rc = d2h(S, L.status, P.status, J.status ? J.status + lo : nullptr, J.pin_status, sizeof(int32_t) * (size_t)n))) return rc;
         // (the estimated indices only: given ones are copied host to host below -- the pinned slot's FA array is the staging area of the
         //  NEXT block's given indices by the time this block is drained)
-        if (J.fa_out && J.estimate_fa && (rc = d2h(S, L.fa, J.fa_out + lo, J.pin_fa_out, sizeof(double) * (size_t)n))) return rc;
+        if (J.fa_out && J.estimate_fa && (rc = d2h(S, L.fa, P.fa, J.fa_out + lo, J.pin_fa_out, sizeof(double) * (size_t)n))) return rc;
+        if ((rc = d2h(S, L.gate, P.gate, J.fa_gate ? J.fa_gate + lo : nullptr, J.pin_gate, sizeof(double) * (size_t)n))) return rc;
         HIPCHK(hipEventRecord(S.ev_out, w->s_out));
         if (c + 1 < mine && (rc = upload(c + 1))) return rc;                       // staged and enqueued while the device works on block c
         if (c >= 1 && (rc = drain(c - 1))) return rc;
@@ -345,10 +432,16 @@ void run_plan(const Job &J, int t, bool need_pin, bool spawned, Outcome *out)
     met2_options opt;
     int rc = met2_plan_get_options(J.plans[t], &opt);
     Work *w = nullptr;
-    if (!rc) rc = ensure_work(J.plans[t], opt.device, J, need_pin, &w);
+    Attach at;
+    {
+        std::lock_guard<std::mutex> lock(g_work_mutex);
+        auto it = g_attach.find(J.plans[t]);
+        if (it != g_attach.end()) at = it->second;
+    }
+    if (!rc) rc = ensure_work(J.plans[t], opt.device, J, need_pin, at, &w);
     if (!rc) {
         DevGuard guard(opt.device);
-        rc = pipeline(J, t, w);
+        rc = pipeline(J, t, w, at);
         if (rc) {
             // nothing of this call may still be in flight when it returns: the caller's arrays are the copies' targets, and the plan must
             // not keep a pending error word
@@ -369,19 +462,11 @@ void run_plan(const Job &J, int t, bool need_pin, bool spawned, Outcome *out)
 extern "C" int met2_plan_attach_fa_spline(met2_plan *plan, met2_plan *plan_lr, int32_t n_lr, const double *alpha_lr, int32_t n_hr, const double *alpha_hr)
 {
     if (!plan) return fail(MET2_E_INVALID, "NULL plan");
-    Work *w;
-    {
+    if (!plan_lr) {                                                                                       // detach
         std::lock_guard<std::mutex> lock(g_work_mutex);
-        Work *&slot = g_work[plan];
-        if (!slot) {
-            met2_options opt;
-            const int rc = met2_plan_get_options(plan, &opt);
-            if (rc) { g_work.erase(plan); return rc; }
-            slot = new Work(); slot->device = opt.device;
-        }
-        w = slot;
+        g_attach.erase(plan);
+        return MET2_OK;
     }
-    if (!plan_lr) { w->plan_lr = nullptr; w->alpha_lr.clear(); w->alpha_hr.clear(); return MET2_OK; }     // detach
     if (plan_lr == plan) return fail(MET2_E_INVALID, "the coarse plan must be another plan");
     if (!alpha_lr || !alpha_hr) return fail(MET2_E_INVALID, "NULL argument");
     int a = 0, b = 0, c = 0, a2 = 0, b2 = 0, c2 = 0;
@@ -395,9 +480,24 @@ extern "C" int met2_plan_attach_fa_spline(met2_plan *plan, met2_plan *plan_lr, i
     if (n_lr != c2 || n_hr != c) return fail(MET2_E_INVALID, "n_lr / n_hr must be the flip-angle counts of the coarse plan and of the plan");
     if (n_lr < 4 || n_lr > 32) return fail(MET2_E_UNSUPPORTED, "coarse FA grid must have 4..32 points");
     for (int i = 1; i < n_lr; ++i) if (!(alpha_lr[i] > alpha_lr[i - 1])) return fail(MET2_E_INVALID, "coarse FA grid must increase");
-    w->plan_lr = plan_lr;
-    w->alpha_lr.assign(alpha_lr, alpha_lr + n_lr);
-    w->alpha_hr.assign(alpha_hr, alpha_hr + n_hr);
+    Attach at;
+    at.plan_lr = plan_lr;
+    at.alpha_lr.assign(alpha_lr, alpha_lr + n_lr);
+    at.alpha_hr.assign(alpha_hr, alpha_hr + n_hr);
+    std::lock_guard<std::mutex> lock(g_work_mutex);
+    g_attach[plan] = std::move(at);
+    return MET2_OK;
+}
+
+// frees the block buffers that destroyed plans left for the next plan on their device
+extern "C" int met2_host_trim(void)
+{
+    std::vector<Work *> take;
+    {
+        std::lock_guard<std::mutex> lock(g_work_mutex);
+        take.swap(g_pool);
+    }
+    for (Work *w : take) free_work(w);
     return MET2_OK;
 }
 
@@ -408,16 +508,25 @@ __attribute__((visibility("hidden"))) void host_release(met2_plan *plan)
     Work *w = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_work_mutex);
+        g_attach.erase(plan);
+        for (auto it = g_attach.begin(); it != g_attach.end();)                  // a coarse plan that goes away takes its attachments with it
+            it = (it->second.plan_lr == plan) ? g_attach.erase(it) : std::next(it);
         auto it = g_work.find(plan);
         if (it != g_work.end()) { w = it->second; g_work.erase(it); }
+        if (w && w->s_in) {
+            int same = 0;
+            for (Work *q : g_pool) same += q->device == w->device;
+            if (same < 2 && g_pool.size() < 32) { g_pool.push_back(w); w = nullptr; }
+        }
     }
     free_work(w);
 }
 }  // namespace met2
 
 extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
-                             int64_t voxel_stride, int64_t echo_stride, const double *fa_index, const uint8_t *mask, int32_t estimate_fa, double *fsol, double *sig,
-                             double *reg, double *lam, double *maps, int32_t *status, double *fa_out, int64_t chunk, double *plan_ms)
+                             int64_t voxel_stride, int64_t echo_stride, const double *mask_values, const double *fa_index, const uint8_t *mask,
+                             int32_t estimate_fa, double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, double *fa_out,
+                             double *fa_gate, int64_t chunk, double *plan_ms)
 {
     if (!plans || n_plans < 1 || n_plans > 64) return fail(MET2_E_INVALID, "met2_fit_host: 1 to 64 plans");
     int nte = 0, nt2 = 0, nfa = 0;
@@ -441,8 +550,8 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     if (estimate_fa == 2) {
         std::lock_guard<std::mutex> lock(g_work_mutex);
         for (int t = 0; t < n_plans; ++t) {
-            auto it = g_work.find(plans[t]);
-            if (it == g_work.end() || !it->second->plan_lr)
+            auto it = g_attach.find(plans[t]);
+            if (it == g_attach.end() || !it->second.plan_lr)
                 return fail(MET2_E_STATE, "estimate_fa = 2 needs met2_plan_attach_fa_spline on every plan first");
         }
     }
@@ -459,15 +568,27 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     Job J;
     J.plans = plans; J.n_plans = n_plans; J.method = method; J.nvox = nvox; J.data = data; J.fa_data = fa_data; J.vs = voxel_stride; J.es = echo_stride;
     J.fa_index = fa_index; J.mask = mask; J.estimate_fa = estimate_fa; J.fsol = fsol; J.sig = sig; J.reg = reg; J.lam = lam; J.maps = maps;
-    J.status = status; J.fa_out = fa_out; J.chunk = chunk; J.nte = nte; J.nt2 = nt2;
+    J.status = status; J.fa_out = fa_out; J.fa_gate = fa_gate; J.mask_values = mask_values; J.chunk = chunk; J.nte = nte; J.nt2 = nt2;
     J.split = getenv("MET2_HOST_NOSPLIT") == nullptr;            // test / A-B switch: whole blocks only
     J.in_case = echo_stride == 1 ? 0 : (voxel_stride == 1 ? 1 : 2);
     if (J.in_case == 0 && voxel_stride < nte) return fail(MET2_E_INVALID, "met2_fit_host: voxel_stride < n_te with echo_stride 1 (overlapping voxels)");
-    J.pin_data = is_pinned(data); J.pin_fa_data = is_pinned(fa_data); J.pin_fa = is_pinned(fa_index); J.pin_mask = is_pinned(mask); J.pin_fsol = is_pinned(fsol);
+    {   // data and fa_data may also lie in DEVICE memory (the volume as a whole-volume filter left it): copied block by block like pinned memory
+        const int kd = mem_kind(data), kf = mem_kind(fa_data);
+        if ((kd == 2 || kf == 2) && J.in_case == 2) return fail(MET2_E_UNSUPPORTED, "met2_fit_host: a device-resident volume needs voxel_stride 1 or echo_stride 1");
+        const void *host_only[] = {fa_index, mask, mask_values, fsol, sig, reg, lam, maps, status, fa_out, fa_gate, plan_ms};
+        for (const void *q : host_only) if (q && mem_kind(q) == 2) return fail(MET2_E_INVALID, "met2_fit_host: only data and fa_data may be device pointers");
+        J.pin_data = kd != 0; J.pin_fa_data = kf != 0;
+    }
+    J.pin_fa = is_pinned(fa_index); J.pin_mask = is_pinned(mask); J.pin_fsol = is_pinned(fsol);
     J.pin_sig = is_pinned(sig); J.pin_reg = is_pinned(reg); J.pin_lam = is_pinned(lam); J.pin_maps = is_pinned(maps);
-    J.pin_status = is_pinned(status); J.pin_fa_out = is_pinned(fa_out);
-    const bool need_pin = !(J.pin_data && J.pin_fa_data && J.in_case != 2 && J.pin_fa && J.pin_mask && J.pin_fsol && J.pin_sig && J.pin_reg && J.pin_lam && J.pin_maps &&
-                            J.pin_status && J.pin_fa_out);
+    J.pin_status = is_pinned(status); J.pin_fa_out = is_pinned(fa_out); J.pin_mv = is_pinned(mask_values); J.pin_gate = is_pinned(fa_gate);
+    Regions &R = J.stage;
+    R.in = !J.pin_data || J.in_case == 2;
+    R.in_fa = fa_data && (!J.pin_fa_data || J.in_case == 2);
+    R.fa = (fa_index && !J.pin_fa) || (fa_out && estimate_fa && !J.pin_fa_out);
+    R.fsol = !J.pin_fsol; R.sig = sig && !J.pin_sig; R.reg = !J.pin_reg; R.lam = lam && !J.pin_lam; R.maps = maps && !J.pin_maps;
+    R.status = status && !J.pin_status; R.mk = mask && !J.pin_mask; R.mv = mask_values && !J.pin_mv; R.gate = fa_gate && !J.pin_gate; R.nlr = 0;
+    const bool need_pin = R.in || R.in_fa || R.fa || R.fsol || R.sig || R.reg || R.lam || R.maps || R.status || R.mk || R.mv || R.gate;
 
     std::vector<Outcome> res(n_plans);
     if (n_plans == 1) run_plan(J, 0, need_pin, false, &res[0]);

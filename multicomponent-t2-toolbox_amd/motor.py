@@ -516,25 +516,35 @@ def _recon_multi_device(data, mask, TE_array, TR, reg_method, reg_matrix, FA_met
     vol_shape, nt = data.shape[:-1], data.shape[-1]
     filtered = denoise not in ("None", None, "none") or (FA_smooth == "yes" and fa_index is None)
     fa_vol = None
+    mvals = None
+
+    def to_pinned(t):                                            # device tensor -> numpy view of a pinned copy in the same memory order
+        h = torch.empty_strided(tuple(t.shape), tuple(t.stride()), dtype=t.dtype, pin_memory=True)
+        h.copy_(t)
+        return h.numpy()
+
+    keep_alive = None
     if filtered:
         dev0 = torch.device("cuda", devices[0])
         dd, _ = _prepare_volume(data, mask, dev0, prepared, denoise)
+        one_device = len(set(devices)) == 1                      # the filtered volume stays where it is: met2_fit_host copies its blocks device to device
+        place = (lambda t: t) if one_device else to_pinned
         if FA_smooth == "yes" and fa_index is None:
             if len(vol_shape) != 3:
                 raise ValueError("FA_smooth='yes' needs data [nx,ny,nz,nt]")
-            fa_vol = gaussian_smooth(dd, 2.0).cpu().numpy()
-        vol = dd.cpu().numpy()                                   # keeps the memory order the volume came in
-        del dd
-    elif prepared:
-        vol = data
+            fa_vol = place(_match_layout(gaussian_smooth(dd, 2.0), "C" if dd.is_contiguous() else "F"))     # laid out like the volume itself
+        if not (dd.is_contiguous() or dd.permute(*reversed(range(dd.dim()))).is_contiguous()):
+            dd = dd.contiguous()
+        vol = place(dd)                                          # keeps the memory order the volume came in
+        keep_alive = dd
+        torch.cuda.current_stream(dev0).synchronize()            # the library's streams do not wait for torch's
     else:
-        vol = data * np.asarray(mask, dtype=np.float64)[..., None]      # motor:180-182
-        np.maximum(vol, 0.0, out=vol)                                    # motor:279
-        if data.flags.f_contiguous and not data.flags.c_contiguous:
-            vol = np.asfortranarray(vol)
-    if not (vol.flags.c_contiguous or vol.flags.f_contiguous):
+        vol = data                                               # prepared inside the library, per block, on the device (mask_values)
+        if not prepared:
+            mvals = np.asarray(mask, dtype=np.float64)
+    if not torch.is_tensor(vol) and not (vol.flags.c_contiguous or vol.flags.f_contiguous):
         vol = np.ascontiguousarray(vol)
-    order = "C" if vol.flags.c_contiguous else "F"
+    order = "C" if (vol.is_contiguous() if torch.is_tensor(vol) else vol.flags.c_contiguous) else "F"
     TE_array = np.asarray(TE_array, dtype=np.float64)
     tau = float(TE_array[1] - TE_array[0])
     Npc = 96 if reg_method == "T2SPARC" else 60
@@ -559,7 +569,12 @@ def _recon_multi_device(data, mask, TE_array, TR, reg_method, reg_matrix, FA_met
                     q.build_dictionary_epg(T2s, T1s, tau, alpha_lr, TR)
                 mhost.attach_fa_spline(plans, coarse, alpha_lr, alpha_values)
                 mode = "spline"
-        out = mhost.fit_host(plans, reg_method, vol, fa_index=fa_index, mask=mask > 0, estimate_fa=mode, fa_data=fa_vol, chunk=PIPELINE_CHUNK if len(devices) == 1 else 0)
+        nvox = int(np.prod(vol_shape))
+        pin = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True).numpy()     # torch's caching host allocator: reused across calls
+        bufs = {"fsol": pin((nvox, Npc)), "sig": pin((nvox, nt)), "reg": pin((nvox,)), "maps": pin((6, nvox)), "status": pin((nvox,), torch.int32),
+                "fa_index": pin((nvox,)), "fa_gate": pin((nvox,))}
+        out = mhost.fit_host(plans, reg_method, vol, fa_index=fa_index, mask=mask > 0, estimate_fa=mode, fa_data=fa_vol, mask_values=mvals, want_gate=True,
+                             chunk=PIPELINE_CHUNK if len(devices) == 1 else 0, out=bufs)
     finally:
         for p in plans + coarse:
             p.close()
@@ -573,15 +588,16 @@ def _recon_multi_device(data, mask, TE_array, TR, reg_method, reg_matrix, FA_met
         return u.transpose(list(range(lead)) + [lead + nd - 1 - i for i in range(nd)] + list(range(lead + nd, u.ndim)))
 
     res = {"fsol_4D": unfold(out["fsol"]), "Est_Signal": unfold(out["sig"]), "reg_param": unfold(out["reg"]), "FA_index": unfold(out["fa_index"])}
-    fa_src = vol if fa_vol is None else fa_vol
-    fitted_fa = (mask > 0) & (fa_src.sum(axis=-1) > 0)            # gate of the FA step (fa_estimation.py:45)
+    fitted_fa = unfold(out["fa_gate"]) > 0                        # gate of the FA step (fa_estimation.py:45), formed on the device per block
     res["FA"] = np.where(fitted_fa, alpha_values[res["FA_index"].astype(int)], 0.0)
     maps = unfold(out["maps"], lead=1)
     for i, name in enumerate(MAP_NAMES):
         res[name] = maps[i]
     res["T2s"] = T2s
     if return_prepared:
-        res["data_prepared"] = vol
+        if mvals is not None:                                     # (plain runs prepare per block inside the library)
+            vol = np.maximum(vol * mvals[..., None], 0.0)
+        res["data_prepared"] = vol.cpu().numpy() if torch.is_tensor(vol) else vol
     return res
 
 

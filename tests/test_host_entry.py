@@ -219,10 +219,10 @@ def test_host_entry_through_raw_ctypes_against_the_oracle(pkg, oracle):
     data, _, _ = synth.make_voxels(nvox, nte=nte, seed=7, device="cpu")
     data = data.numpy()
     fsol = np.empty((nvox, nt2)); reg = np.empty(nvox); maps = np.empty((6, nvox)); ms = np.zeros(2)
-    L.met2_fit_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + \
-        [C.c_void_p] * 7 + [C.c_int64, C.c_void_p]
-    rc = L.met2_fit_host(plans, 2, 2, nvox, data.ctypes.data, None, nte, 1, None, None, 0, fsol.ctypes.data, None, reg.ctypes.data, None,
-                         maps.ctypes.data, None, None, 128, ms.ctypes.data)
+    L.met2_fit_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32] + \
+        [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]
+    rc = L.met2_fit_host(plans, 2, 2, nvox, data.ctypes.data, None, nte, 1, None, None, None, 0, fsol.ctypes.data, None, reg.ctypes.data, None,
+                         maps.ctypes.data, None, None, None, 128, ms.ctypes.data)
     assert rc == 0, L.met2_last_error()
     for i in range(2):
         assert L.met2_plan_destroy(C.c_void_p(plans[i])) == 0
@@ -323,3 +323,27 @@ def test_driver_with_a_device_list_equals_the_default_driver(pkg, order, denoise
         a = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
         b = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True, devices=devices)
         assert np.array_equal(a["data_prepared"], b["data_prepared"]) and np.array_equal(a["MWF"], b["MWF"], equal_nan=True)
+
+
+@gpu
+def test_mask_values_and_the_fa_gate(pkg):
+    """mask_values: data *= mask, clip at 0 on the device per block (motor:180-182, :279); fa_gate: mask and a positive echo sum of what the
+    FA step sees (fa_estimation.py:45)"""
+    host = importlib.import_module(PKG + ".host")
+    synth = importlib.import_module(PKG + ".synth")
+    plans, alphas, _, _ = _plans(pkg, 2, nfa=16)
+    nvox = 7_000
+    data, _, _ = synth.make_voxels(nvox, nte=32, seed=17, fa_values=alphas, device="cpu")
+    data = data.numpy()
+    rng = np.random.default_rng(3)
+    data[rng.integers(0, nvox, 50), rng.integers(0, 32, 50)] *= -1.0
+    mv = rng.choice([0.0, 1.0, 1.0, 1.0, 2.0], nvox)
+    mask = (mv > 0).astype(np.uint8)
+    prepared = np.maximum(data * mv[:, None], 0.0)
+    for layout in ("C", "F"):
+        raw = data if layout == "C" else np.asfortranarray(data)
+        ref = host.fit_host(plans, "X2", prepared, mask=mask, estimate_fa=True, chunk=1500, want_lambda=True, want_gate=True)
+        got = host.fit_host(plans, "X2", raw, mask=mask, mask_values=mv, estimate_fa=True, chunk=1500, want_lambda=True, want_gate=True)
+        _same(got, ref, keys=("fsol", "sig", "reg", "lam", "maps", "status", "fa_index", "fa_gate"))
+        assert np.array_equal(got["fa_gate"], ((prepared.sum(axis=1) > 0) & (mask > 0)).astype(np.float64))
+        assert np.array_equal(raw, data)                                # the caller's array is never written

@@ -348,8 +348,8 @@ def test_fit_host_argument_checks_need_no_gpu():
     with pytest.raises(ValueError, match="no plan"):
         host.fit_host([], "X2", np.zeros((4, 32)))
     L = lib.lib()
-    assert L.met2_fit_host(None, 0, 2, 0, None, None, 32, 1, None, None, 0, None, None, None, None, None, None, None, 0, None) == -1
+    assert L.met2_fit_host(None, 0, 2, 0, None, None, 32, 1, None, None, None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
     assert b"1 to 64 plans" in L.met2_last_error()
     arr = (C.c_void_p * 1)(None)
-    assert L.met2_fit_host(arr, 1, 2, 0, None, None, 32, 1, None, None, 0, None, None, None, None, None, None, None, 0, None) == -1
+    assert L.met2_fit_host(arr, 1, 2, 0, None, None, 32, 1, None, None, None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
     assert b"NULL plan" in L.met2_last_error()
