@@ -374,6 +374,8 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
     vol_shape = data.shape[:-1]
     nt = data.shape[-1]
     mask = np.asarray(mask).reshape(vol_shape)
+    if devices is None and DRIVER_THROUGH_C_ABI and plan is None and not distributed and data.ndim >= 2:
+        devices = [device]                                       # the default: one device, through the C ABI's host entry (the switch says why)
     if devices is not None:
         if plan is not None or distributed:
             raise ValueError("devices=[...] builds its own plans and does not go with distributed=True")
@@ -427,6 +429,12 @@ def recon_met2_arrays(data, mask, TE_array, TR, reg_method="X2", reg_matrix="L2"
             plan.close()
 
 
+# recon_met2_arrays without a caller's plan goes through met2_fit_host (csrc/met2_host.hip: the chunk pipeline inside the library, one host
+# thread, three streams, the driver's preparation and the FA gate as kernels on the block) instead of fit_host_pipeline (the same pipeline
+# as torch calls): 128x128x64x32 phantom, pageable numpy volume in, ten arrays out: spline FA 0.095 -> 0.085 s, TV + FA smoothing + spline
+# 0.133 -> 0.122 s, brute-force FA 0.136 -> 0.122 s (profiles/r04_driver_device_list.jsonl).  False: the torch pipeline (kept: it serves callers
+# who bring their own plan, and the tests compare the two bit for bit).
+DRIVER_THROUGH_C_ABI = True
 ONE_SHOT_PIPELINE = True      # denoised / FA-smoothed runs: the fit is chunked over the device-resident volume and the outputs leave under it (False: one fit call, then .cpu())
 PIPELINE_CHUNK = 262144       # voxels per chunk of the driver's host pipeline (67 MB in, 200 MB out at 32 echoes / 60 bins; measured 65 536 / 131 072 / 262 144: 207 / 170-190 / 165 ms per Mi voxels)
 

@@ -313,14 +313,23 @@ def test_driver_with_a_device_list_equals_the_default_driver(pkg, order, denoise
     keep = motor.PIPELINE_CHUNK
     try:
         motor.PIPELINE_CHUNK = 700
+        motor.DRIVER_THROUGH_C_ABI = False                          # the torch pipeline (fit_host_pipeline) on one device
         ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given)
+        motor.DRIVER_THROUGH_C_ABI = True
         got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given, devices=devices)
+        dflt = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given)
     finally:
         motor.PIPELINE_CHUNK = keep
+        motor.DRIVER_THROUGH_C_ABI = True
+    assert np.array_equal(dflt["fsol_4D"], ref["fsol_4D"], equal_nan=True) and np.array_equal(dflt["FA"], ref["FA"])
     for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
         assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), k
     if denoise == "TV":                                             # the file-level driver saves the denoised volume (motor:302-303)
-        a = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
+        motor.DRIVER_THROUGH_C_ABI = False
+        try:
+            a = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
+        finally:
+            motor.DRIVER_THROUGH_C_ABI = True
         b = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True, devices=devices)
         assert np.array_equal(a["data_prepared"], b["data_prepared"]) and np.array_equal(a["MWF"], b["MWF"], equal_nan=True)
 

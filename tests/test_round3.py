@@ -275,6 +275,16 @@ def test_singular_penalty_runs_unseeded_and_fits_like_the_oracle(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("order,fa_method", [("C", "brute-force"), ("F", "brute-force"), ("F", "spline")])
 def test_driver_pipeline_equals_one_shot(order, fa_method):
+    # (the torch pipeline of the driver: since late round 4 the default driver goes through met2_fit_host -- tests/test_host_entry.py compares the two)
+    motor = importlib.import_module(PKG + ".motor")
+    motor.DRIVER_THROUGH_C_ABI = False
+    try:
+        _test_driver_pipeline_equals_one_shot_impl(order, fa_method)
+    finally:
+        motor.DRIVER_THROUGH_C_ABI = True
+
+
+def _test_driver_pipeline_equals_one_shot_impl(order, fa_method):
     # recon_met2_arrays streams a plain run (no denoising, no FA smoothing) through the chunked host pipeline; return_prepared=True
     # takes the one-shot path (whole volume on the device).  Same ten outputs bit for bit, for C- and Fortran-ordered (nibabel)
     # volumes, with zero and non-unit mask values, negative samples (clipped, motor:279) and a ragged last chunk.

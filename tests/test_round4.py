@@ -446,6 +446,16 @@ def test_bench_tv_workload_line():
 @pytest.mark.parametrize("order,denoise,smooth,fa_method", [("C", "TV", "yes", "spline"), ("F", "TV", "yes", "spline"), ("F", "NESMA", "no", "brute-force"),
                                                             ("C", "None", "yes", "brute-force"), ("F", "None", "yes", "spline")])
 def test_filtered_runs_are_chunked_on_the_device(order, denoise, smooth, fa_method):
+    # (the torch pipeline of the driver: since late round 4 the default driver goes through met2_fit_host -- tests/test_host_entry.py compares the two)
+    motor = importlib.import_module(PKG + ".motor")
+    motor.DRIVER_THROUGH_C_ABI = False
+    try:
+        _test_filtered_runs_are_chunked_on_the_device_impl(order, denoise, smooth, fa_method)
+    finally:
+        motor.DRIVER_THROUGH_C_ABI = True
+
+
+def _test_filtered_runs_are_chunked_on_the_device_impl(order, denoise, smooth, fa_method):
     # A denoised or FA-smoothed run filters the whole volume on the device, then feeds the FA step and the fit in chunks of the device-resident
     # voxel list while the outputs of earlier chunks are copied out (motor._recon_pipelined, on_device); return_prepared=True keeps the one-call
     # path.  Same ten outputs bit for bit, both memory orders, ragged last chunk, zero / non-unit mask values, negative samples.
