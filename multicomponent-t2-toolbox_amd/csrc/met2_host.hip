@@ -557,8 +557,12 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     }
     if (chunk < 0) return fail(MET2_E_INVALID, "chunk < 0");
     if (chunk == 0) {
-        // four blocks per plan so that the copies of a plan's first and last block (the only ones not under a fit) are a quarter of its
-        // share, in multiples of 4 096 voxels, at most 262 144 (0.29 GB per slot at 32 x 60)
+        // four blocks per plan (each plan splits its first and last one further), in multiples of 4 096 voxels, at most 262 144 (0.29 GB per
+        // slot at 32 x 60).  Every block ends with the tail of its persistent kernel and a small clean-up pass (~1.9 ms), which speaks for
+        // large blocks -- configs[1] (X2 on every voxel, 150 ms of kernels against 42 ms of copies), one plan, blocks of 262 144 / 524 288 /
+        // 1 048 576 voxels: 166.1 / 161.6 / 160.7 ms -- but a block's download only hides under the NEXT block's kernels, which speaks for
+        // small ones where the device is fast: the driver on the half-masked phantom (75 ms of kernels, the same 42 ms of copies) 0.085 s at
+        // 262 144 against 0.090 s at 524 288.  The driver's case decides.
         const int64_t per = (nvox + (int64_t)n_plans * 4 - 1) / ((int64_t)n_plans * 4);
         chunk = std::min<int64_t>(262144, std::max<int64_t>(4096, (per + 4095) / 4096 * 4096));
     }

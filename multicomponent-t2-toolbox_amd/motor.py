@@ -582,7 +582,7 @@ def _recon_multi_device(data, mask, TE_array, TR, reg_method, reg_matrix, FA_met
         bufs = {"fsol": pin((nvox, Npc)), "sig": pin((nvox, nt)), "reg": pin((nvox,)), "maps": pin((6, nvox)), "status": pin((nvox,), torch.int32),
                 "fa_index": pin((nvox,)), "fa_gate": pin((nvox,))}
         out = mhost.fit_host(plans, reg_method, vol, fa_index=fa_index, mask=mask > 0, estimate_fa=mode, fa_data=fa_vol, mask_values=mvals, want_gate=True,
-                             chunk=PIPELINE_CHUNK if len(devices) == 1 else 0, out=bufs)
+                             chunk=PIPELINE_CHUNK if PIPELINE_CHUNK != 262144 else 0, out=bufs)     # (0: the library's block size; a test that sets PIPELINE_CHUNK gets its chunks)
     finally:
         for p in plans + coarse:
             p.close()
