@@ -209,12 +209,28 @@ __global__ __launch_bounds__(64) void gcv_basis_kernel(int m, int n, const doubl
 // voxel classification and counting sort by FA index
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void classify_kernel(int64_t nvox, int nte, int nfa, const double *__restrict__ data,
+// counters and cursors of a fit start at zero: ONE launch instead of two or three fills (a fit over a block of a host pipeline starts while the previous
+// block's download bursts, and every tiny launch then waits its turn: three fills stood 1.8 ms in a 5 ms gap between two blocks' solver kernels).
+// keep_err: the error word keeps what earlier ENQUEUED fits may have set.
+__global__ __launch_bounds__(256) void reset_sort_kernel(SortBufs sb, int nfa, int keep_err)
+{
+    const int e = 4 * (nfa + 1) + 1;                                  // index of the error word behind hist | cursor | bucket_start | chunk_start | queue
+    for (int i = threadIdx.x; i < e + 15; i += blockDim.x)
+        if (i != e || !keep_err) sb.hist[i] = 0;
+}
+
+#define MET2_SORT_BLOCK 1024
+// The histogram and the cursors take ONE global atomic per (workgroup, flip angle): a wave adds its counts to a table in LDS first.  With one atomic
+// per wave a single-angle fit sent 3 600 atomics per 230 000 voxels to one address -- 0.33 ms of classify and 0.75 ms of scatter were that queue.
+__global__ __launch_bounds__(MET2_SORT_BLOCK) void classify_kernel(int64_t nvox, int nte, int nfa, const double *__restrict__ data,
                                                        int64_t vs, int64_t es,      // element strides of data: voxel, echo
                                                        const double *__restrict__ fa_index, const uint8_t *__restrict__ mask,
                                                        int require_first_echo, SortBufs sb, int32_t *__restrict__ status)
 {
+    extern __shared__ int sort_lds[];                                 // [nfa] counts of this workgroup
     const int lane = lane_id();
+    for (int i = threadIdx.x; i < nfa; i += blockDim.x) sort_lds[i] = 0;
+    __syncthreads();
     int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int key = -1, st = 0;
     if (v < nvox) {
@@ -231,50 +247,64 @@ __global__ __launch_bounds__(256) void classify_kernel(int64_t nvox, int nte, in
         sb.key[v] = key;
         if (status) status[v] = st;
     }
-    // wave-aggregated histogram
+    // wave-aggregated histogram, into the workgroup's table
     u64 todo = ballot(key >= 0);
     while (todo) {
         int leader = first_lane(todo);
         int k0 = bcast_i(key, leader);
         u64 same = ballot(key == k0) & todo;
-        if (lane == leader) atomicAdd(&sb.hist[k0], __popcll(same));
+        if (lane == leader) atomicAdd(&sort_lds[k0], __popcll(same));
         todo &= ~same;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfa; i += blockDim.x) { const int c = sort_lds[i]; if (c) atomicAdd(&sb.hist[i], c); }
 }
 
-__global__ void scan_kernel(int nfa, int chunk, SortBufs sb)
+// bucket and chunk offsets from the histogram.  The histogram comes in and the offsets go out in parallel; the running sums are taken over LDS (one
+// thread walking 273 counters in global memory stood 0.13 ms per launch, two launches per fit).
+__global__ __launch_bounds__(256) void scan_kernel(int nfa, int chunk, SortBufs sb)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    extern __shared__ int sort_lds[];                                 // [nfa + 1] bucket starts, [nfa + 1] chunk starts
+    int *bs = sort_lds, *cs = sort_lds + nfa + 1;
+    for (int f = threadIdx.x; f < nfa; f += blockDim.x) { const int c = sb.hist[f]; bs[f] = c; cs[f] = (c + chunk - 1) / chunk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int acc = 0, cacc = 0;
-        for (int f = 0; f < nfa; ++f) {
-            sb.bucket_start[f] = acc; sb.chunk_start[f] = cacc; sb.cursor[f] = 0;
-            int c = sb.hist[f];
-            acc += c; cacc += (c + chunk - 1) / chunk;
-        }
-        sb.bucket_start[nfa] = acc; sb.chunk_start[nfa] = cacc;
+        for (int f = 0; f < nfa; ++f) { const int c = bs[f], cc = cs[f]; bs[f] = acc; cs[f] = cacc; acc += c; cacc += cc; }
+        bs[nfa] = acc; cs[nfa] = cacc;
         sb.queue[0] = 0;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f <= nfa; f += blockDim.x) {
+        sb.bucket_start[f] = bs[f]; sb.chunk_start[f] = cs[f];
+        if (f < nfa) sb.cursor[f] = 0;
     }
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(int64_t nvox, SortBufs sb)
+__global__ __launch_bounds__(MET2_SORT_BLOCK) void scatter_kernel(int64_t nvox, int nfa, SortBufs sb)
 {
+    extern __shared__ int sort_lds[];                                 // [nfa] counts of this workgroup, then [nfa] its base in every bucket
     const int lane = lane_id();
+    for (int i = threadIdx.x; i < nfa; i += blockDim.x) sort_lds[i] = 0;
+    __syncthreads();
     int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int key = (v < nvox) ? sb.key[v] : -1;
+    int off = 0;                                                      // this voxel's place among the workgroup's voxels of its flip angle
     u64 todo = ballot(key >= 0);
     while (todo) {
         int leader = first_lane(todo);
         int k0 = bcast_i(key, leader);
         u64 same = ballot(key == k0) & todo;
         int base = 0;
-        if (lane == leader) base = atomicAdd(&sb.cursor[k0], __popcll(same));
+        if (lane == leader) base = atomicAdd(&sort_lds[k0], __popcll(same));
         base = bcast_i(base, leader);
-        if (key == k0) {
-            int rank = __popcll(same & ((1ull << lane) - 1ull));
-            sb.perm[sb.bucket_start[k0] + base + rank] = (int)v;
-        }
+        if (key == k0) off = base + __popcll(same & ((1ull << lane) - 1ull));
         todo &= ~same;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfa; i += blockDim.x) { const int c = sort_lds[i]; if (c) sort_lds[nfa + i] = atomicAdd(&sb.cursor[i], c); }
+    __syncthreads();
+    if (key >= 0) sb.perm[sb.bucket_start[key] + sort_lds[nfa + key] + off] = (int)v;
 }
 
 // second pass of the capacity scheme: voxels whose passive set hit the fast path's kmax are queued again
@@ -1794,12 +1824,17 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     }
     if (!p->have_t2) HIPCHK(hipMemsetAsync(p->dT2, 0, sizeof(double) * 128, s));
     SortBufs sb = sort_bufs(p);
-    {   // counters and cursors start at zero; the error word (index 4 (nfa + 1) + 1) keeps what earlier ENQUEUED fits may have set
-        const size_t e = 4 * (size_t)(p->n_fa + 1) + 1;
-        HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (p->err_pending ? e : e + 1), s));
-        HIPCHK(hipMemsetAsync(p->dSmall + e + 1, 0, sizeof(int) * 14, s));
-    }
+    // counters and cursors start at zero; the error word (index 4 (nfa + 1) + 1) keeps what earlier ENQUEUED fits may have set
+    hipLaunchKernelGGL(reset_sort_kernel, dim3(1), dim3(256), 0, s, sb, p->n_fa, p->err_pending ? 1 : 0);
     const int nb = (int)((nvox + 255) / 256);
+    const int nbs = (int)((nvox + MET2_SORT_BLOCK - 1) / MET2_SORT_BLOCK);          // classify / scatter: one global atomic per (workgroup, flip angle)
+    const size_t sort_lds = sizeof(int) * 2 * ((size_t)p->n_fa + 1);                // per-flip-angle tables of the sort kernels in LDS
+    if (sort_lds > 48 * 1024) {
+        if (sort_lds > 150 * 1024) return fail(MET2_E_UNSUPPORTED, "more than 19 000 flip angles (or ROIs) in one plan");
+        HIPCHK(hipFuncSetAttribute((const void *)classify_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        HIPCHK(hipFuncSetAttribute((const void *)scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        HIPCHK(hipFuncSetAttribute((const void *)scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+    }
     // work-queue granularity: every wave pulls
     // its own voxels -- one at a time for the methods that spend ~1 ms per voxel (X2/L2 on configs[1]: 1 / 2 / 4 / 8 / 16
     // voxels per pull -> 5.37 / 5.32 / 5.22 / 5.04 / 4.71 M voxels/s; HBM writes 1.01 / 0.93 / 0.88 / 0.89 GB because the
@@ -1809,10 +1844,10 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     chunk = tuning_env("MET2_CHUNK", 1, 1024, chunk);
     const bool dbg = getenv("MET2_DEBUG") != nullptr;
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] fit: nvox=%lld grid=%d block=%d lds=%d\n", (long long)nvox, g.grid, g.block, g.lds); fflush(stderr); }
-    hipLaunchKernelGGL(classify_kernel, dim3(nb), dim3(256), 0, s, nvox, p->n_te, p->n_fa, data, voxel_stride, echo_stride, fa_index, mask, 1, sb, status);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
+    hipLaunchKernelGGL(classify_kernel, dim3(nbs), dim3(MET2_SORT_BLOCK), sort_lds, s, nvox, p->n_te, p->n_fa, data, voxel_stride, echo_stride, fa_index, mask, 1, sb, status);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), sort_lds, s, p->n_fa, chunk, sb);
     if (dbg) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[met2] classify done\n"); fflush(stderr); }
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nbs), dim3(MET2_SORT_BLOCK), sort_lds, s, nvox, p->n_fa, sb);
     HIPCHK(hipGetLastError());
     if (dbg) {
         HIPCHK(hipStreamSynchronize(s));
@@ -1864,11 +1899,10 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
         // gated-out voxels are finalised from the first pass's keys, then the key/perm buffers are reused
         hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
                            sig, reg, lam, maps);
-        HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 1), s));     // all but the error word
-        HIPCHK(hipMemsetAsync(sb.xq, 0, sizeof(int) * 8, s));
+        hipLaunchKernelGGL(reset_sort_kernel, dim3(1), dim3(256), 0, s, sb, p->n_fa, 1);              // all but the error word
         hipLaunchKernelGGL(requeue_overflow_kernel, dim3(nb), dim3(256), 0, s, nvox, fa_index, status, sb);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
-        hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), sort_lds, s, p->n_fa, chunk, sb);
+        hipLaunchKernelGGL(scatter_kernel, dim3(nbs), dim3(MET2_SORT_BLOCK), sort_lds, s, nvox, p->n_fa, sb);
         HIPCHK(hipGetLastError());
         FitArgs A2 = A;
         const int kmid = mid_kmax(p, kmeth, kfast);
@@ -1879,11 +1913,10 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
             A2.kmax = gm.kmax; A2.waves = gm.waves; A2.wave_doubles = gm.wave_doubles;
             rc = launch_method(kmeth, A2, gm, s, true);
             if (rc) return rc;
-            HIPCHK(hipMemsetAsync(p->dSmall, 0, sizeof(int) * (4 * (size_t)(p->n_fa + 1) + 1), s));
-            HIPCHK(hipMemsetAsync(sb.xq, 0, sizeof(int) * 8, s));
+            hipLaunchKernelGGL(reset_sort_kernel, dim3(1), dim3(256), 0, s, sb, p->n_fa, 1);
             hipLaunchKernelGGL(requeue_overflow_kernel, dim3(nb), dim3(256), 0, s, nvox, fa_index, status, sb);
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(64), 0, s, p->n_fa, chunk, sb);
-            hipLaunchKernelGGL(scatter_kernel, dim3(nb), dim3(256), 0, s, nvox, sb);
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(256), sort_lds, s, p->n_fa, chunk, sb);
+            hipLaunchKernelGGL(scatter_kernel, dim3(nbs), dim3(MET2_SORT_BLOCK), sort_lds, s, nvox, p->n_fa, sb);
             HIPCHK(hipGetLastError());
         }
         A2.kmax = g2.kmax; A2.waves = g2.waves; A2.wave_doubles = g2.wave_doubles;
