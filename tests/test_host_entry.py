@@ -356,3 +356,41 @@ def test_mask_values_and_the_fa_gate(pkg):
         _same(got, ref, keys=("fsol", "sig", "reg", "lam", "maps", "status", "fa_index", "fa_gate"))
         assert np.array_equal(got["fa_gate"], ((prepared.sum(axis=1) > 0) & (mask > 0)).astype(np.float64))
         assert np.array_equal(raw, data)                                # the caller's array is never written
+
+
+@gpu
+def test_concurrent_calls_pool_reuse_and_trim(pkg):
+    """two host threads in met2_fit_host at once (each with its own plan); a destroyed plan's block buffers serve the next plan on the device;
+    met2_host_trim frees what waits; a different shape adopts pooled buffers and regrows them"""
+    import threading
+    host = importlib.import_module(PKG + ".host")
+    synth = importlib.import_module(PKG + ".synth")
+    lib = importlib.import_module(PKG + "._lib")
+    plans, alphas, _, _ = _plans(pkg, 2)
+    nvox = 12_000
+    data, fa, _ = synth.make_voxels(nvox, nte=32, seed=41, fa_values=alphas, device="cpu")
+    data, fa = data.numpy(), fa.numpy()
+    ref = _reference_fit(plans[0], "X2", data, fa)
+    res = [None, None]
+
+    def work(i):
+        for _ in range(3):
+            res[i] = host.fit_host(plans[i], "X2", data, fa_index=fa, chunk=2000 + 500 * i, want_lambda=True)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    _same(res[0], ref); _same(res[1], ref)
+    for p in plans:
+        p.close()                                                    # their buffers wait for the next plans on device 0
+    again, _, _, _ = _plans(pkg, 2)
+    _same(host.fit_host(again, "X2", data, fa_index=fa, chunk=1500, want_lambda=True), ref)
+    # another shape on the same device: NNLS at 48 x 120 adopts the pooled buffers and regrows them
+    for p in again:
+        p.close()
+    big, alphas2, _, _ = _plans(pkg, 1, nte=48, nt2=120, nfa=3)
+    d2, fa2, _ = synth.make_voxels(3_000, nte=48, seed=5, fa_values=alphas2, device="cpu")
+    _same(host.fit_host(big, "T2SPARC", d2.numpy(), fa_index=fa2.numpy(), chunk=700, want_lambda=True), _reference_fit(big[0], "T2SPARC", d2.numpy(), fa2.numpy()))
+    big[0].close()
+    assert lib.lib().met2_host_trim() == 0 and lib.lib().met2_host_trim() == 0
+    fresh, _, _, _ = _plans(pkg, 1)
+    _same(host.fit_host(fresh, "NNLS", data, fa_index=fa, want_lambda=True), _reference_fit(fresh[0], "NNLS", data, fa))
