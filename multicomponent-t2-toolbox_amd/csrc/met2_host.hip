@@ -523,7 +523,7 @@ __attribute__((visibility("hidden"))) void host_release(met2_plan *plan)
 }
 }  // namespace met2
 
-extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
+static int fit_host_impl(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
                              int64_t voxel_stride, int64_t echo_stride, const double *mask_values, const double *fa_index, const uint8_t *mask,
                              int32_t estimate_fa, double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, double *fa_out,
                              double *fa_gate, int64_t chunk, double *plan_ms)
@@ -598,11 +598,33 @@ extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t m
     if (n_plans == 1) run_plan(J, 0, need_pin, false, &res[0]);
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < n_plans; ++t) th.emplace_back(run_plan, std::cref(J), t, need_pin, true, &res[t]);
+        th.reserve((size_t)n_plans);
+        try {
+            for (int t = 0; t < n_plans; ++t) th.emplace_back(run_plan, std::cref(J), t, need_pin, true, &res[t]);
+        } catch (...) {                       // a thread could not be started: the ones that run finish their share first
+            for (auto &x : th) x.join();
+            throw;
+        }
         for (auto &x : th) x.join();
     }
     if (plan_ms) for (int t = 0; t < n_plans; ++t) plan_ms[t] = res[t].ms;
     for (int t = 0; t < n_plans; ++t)
         if (res[t].rc) return fail(res[t].rc, "met2_fit_host, plan " + std::to_string(t) + ": " + res[t].msg);
     return MET2_OK;
+}
+
+// the C boundary lets no C++ exception through (a thread that cannot be started, an allocation that fails)
+extern "C" int met2_fit_host(met2_plan *const *plans, int32_t n_plans, int32_t method, int64_t nvox, const double *data, const double *fa_data,
+                             int64_t voxel_stride, int64_t echo_stride, const double *mask_values, const double *fa_index, const uint8_t *mask,
+                             int32_t estimate_fa, double *fsol, double *sig, double *reg, double *lam, double *maps, int32_t *status, double *fa_out,
+                             double *fa_gate, int64_t chunk, double *plan_ms)
+{
+    try {
+        return fit_host_impl(plans, n_plans, method, nvox, data, fa_data, voxel_stride, echo_stride, mask_values, fa_index, mask, estimate_fa, fsol, sig, reg, lam,
+                             maps, status, fa_out, fa_gate, chunk, plan_ms);
+    } catch (const std::exception &e) {
+        return fail(MET2_E_HIP, std::string("met2_fit_host: ") + e.what());
+    } catch (...) {
+        return fail(MET2_E_HIP, "met2_fit_host: unknown C++ exception");
+    }
 }
