@@ -2,8 +2,9 @@
 
 The reference's driver holds its volume in host memory (motor:167-182) and loops over image rows in one process (motor:427-441);
 this is that loop handed to the library: blocks of voxels are dealt to the plans (one per device, each driven by its own host thread
-inside the C call), copied in, fitted and copied out on three streams per device.  No torch here: the arrays are the caller's numpy
-arrays, staged through pinned block buffers inside the library (arrays that already live in pinned memory are used in place)."""
+inside the C call), copied in, fitted and copied out on three streams per device.  torch is not on this call path (ctypes + numpy; the package
+imports it for Met2Plan, which owns the plan handles): the arrays are the caller's numpy arrays, staged through pinned block buffers inside the
+library (arrays that already live in pinned memory are used in place; a float64 tensor on the device may stand where the volume does)."""
 import ctypes as C
 
 import numpy as np
