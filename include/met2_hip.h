@@ -205,7 +205,8 @@ int met2_plan_finish(met2_plan *plan, void *stream);
  *   fa_out [nvox]     out, may be NULL: the FA index every voxel was fitted with
  *   fa_gate [nvox]    out, may be NULL: 1.0 where the FA step's gate holds (fa_estimation.py:45: mask and a positive echo sum of what
  *                     the FA step sees), else 0.0 -- the driver reports a flip angle only there (motor:366-370)
- *   chunk             voxels per block; 0 = a quarter of a plan's share, in multiples of 4 096, at most 262 144
+ *   chunk             voxels per block; 0 = a quarter of a plan's share, in multiples of 4 096, at most 262 144 and (unless the share itself is
+ *                     smaller) at least 65 536
  *   plan_ms [n_plans] out, may be NULL: wall-clock ms every plan's thread spent in the call
  * Blocking.  Every voxel is solved on its own, so the outputs are bit for bit those of one met2_fit over the whole list, whatever
  * n_plans, chunk and the devices.  Returns the first failing plan's code (an FA index outside the dictionary: MET2_E_INVALID) after

@@ -252,7 +252,7 @@ int pipeline(const Job &J, int t, Work *w, const Attach &at)
     std::vector<std::pair<int64_t, int64_t>> seg;           // (first voxel, voxels)
     for (int64_t b = t; b < nblocks; b += J.n_plans) seg.emplace_back(b * chunk, std::min<int64_t>(chunk, J.nvox - b * chunk));
     if (J.split && !seg.empty()) {
-        auto eighth = [](int64_t n) { return n >= 32768 ? std::max<int64_t>(4096, (n / 8) & ~(int64_t)4095) : 0; };
+        auto eighth = [](int64_t n) { return n >= 131072 ? std::max<int64_t>(4096, (n / 8) & ~(int64_t)4095) : 0; };      // (smaller blocks are not worth two more pieces)
         {   const auto last = seg.back(); const int64_t e = eighth(last.second);
             if (e) { seg.back() = {last.first, last.second - e}; seg.emplace_back(last.first + last.second - e, e); } }
         {   const auto first = seg.front(); const int64_t e = eighth(first.second);
@@ -563,8 +563,10 @@ static int fit_host_impl(met2_plan *const *plans, int32_t n_plans, int32_t metho
         // 1 048 576 voxels: 166.1 / 161.6 / 160.7 ms -- but a block's download only hides under the NEXT block's kernels, which speaks for
         // small ones where the device is fast: the driver on the half-masked phantom (75 ms of kernels, the same 42 ms of copies) 0.085 s at
         // 262 144 against 0.090 s at 524 288.  The driver's case decides.
+        // With many plans the share of each is small; blocks are then not cut below 65 536 voxels (a 6.5 ms fit against ~2 ms per block).
+        const int64_t share = (nvox + n_plans - 1) / n_plans;
         const int64_t per = (nvox + (int64_t)n_plans * 4 - 1) / ((int64_t)n_plans * 4);
-        chunk = std::min<int64_t>(262144, std::max<int64_t>(4096, (per + 4095) / 4096 * 4096));
+        chunk = std::min<int64_t>(262144, std::max<int64_t>(std::min<int64_t>(65536, share), (per + 4095) / 4096 * 4096));
     }
     chunk = std::min<int64_t>(chunk, nvox);
     if (chunk > 0x7fffffff) return fail(MET2_E_INVALID, "chunk out of range");
