@@ -394,3 +394,25 @@ def test_concurrent_calls_pool_reuse_and_trim(pkg):
     assert lib.lib().met2_host_trim() == 0 and lib.lib().met2_host_trim() == 0
     fresh, _, _, _ = _plans(pkg, 1)
     _same(host.fit_host(fresh, "NNLS", data, fa_index=fa, want_lambda=True), _reference_fit(fresh[0], "NNLS", data, fa))
+
+
+@gpu
+def test_full_size_volume_through_the_host_entry(pkg):
+    """configs[2]'s size (200 x 200 x 128 = 5.12 M voxels, L-curve / L1): byte offsets beyond 2^31 in every big array, twenty blocks over two plans,
+    pageable arrays -- equal to one met2_fit over the list on every output, every status word FITTED"""
+    import torch
+    host = importlib.import_module(PKG + ".host")
+    synth = importlib.import_module(PKG + ".synth")
+    plans, alphas, _, _ = _plans(pkg, 2, nfa=1, penalty="L1")
+    nvox = 200 * 200 * 128
+    data, _, _ = synth.make_voxels(nvox, nte=32, seed=20260103, device="cuda")
+    out = plans[0].fit("L_curve", data, want_lambda=True)
+    torch.cuda.synchronize()
+    ref = {k: v.cpu().numpy() for k, v in out.items()}
+    del out
+    d = data.cpu().numpy()
+    del data
+    res = host.fit_host(plans, "L_curve", d, want_lambda=True)
+    _same(res, ref)
+    assert (res["status"] == 1).all()
+    assert res["plan_ms"].min() > 0
