@@ -1,0 +1,26 @@
+"""met2_fit_host host-to-host rates per method on a 128x128x64 volume at 32x60 (pinned arrays, one plan): the light methods are bound by the copies."""
+import importlib, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+PKG = "multicomponent-t2-toolbox_amd"
+pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth"); host = importlib.import_module(PKG + ".host")
+nte, nt2, nvox = 32, 60, 128 * 128 * 64
+T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+p = pkg.Met2Plan(nte, nt2, 1); p.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty("L2", T2s)
+data, _, _ = synth.make_voxels(nvox, nte=nte, seed=20260102, device="cuda")
+pin = torch.empty(data.shape, dtype=torch.float64, pin_memory=True).copy_(data); torch.cuda.synchronize()
+P = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True).numpy()
+out = {"fsol": P((nvox, nt2)), "sig": P((nvox, nte)), "reg": P((nvox,)), "maps": P((6, nvox)), "status": P((nvox,), torch.int32), "fa_index": P((nvox,))}
+for method in ("NNLS", "T2SPARC", "X2", "L_curve", "GCV", "BayesReg"):
+    torch.cuda.synchronize()
+    dev = None
+    for i in range(3):
+        t0 = time.perf_counter(); r = p.fit(method, data); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if i: dev = dt if dev is None else min(dev, dt)
+    del r
+    best = None
+    for i in range(4):
+        t0 = time.perf_counter(); out = host.fit_host(p, method, pin.numpy(), out=out); dt = time.perf_counter() - t0
+        if i: best = dt if best is None else min(best, dt)
+    print(json.dumps({"method": method, "device_resident_ms": round(1e3 * dev, 2), "host_to_host_ms": round(1e3 * best, 2), "host_to_host_voxels_per_s": round(nvox / best),
+                      "host_bytes_per_voxel": 8 * (2 * nte + nt2 + 9) + 4, "pcie_GBps": round(nvox * (8 * (2 * nte + nt2 + 9) + 4) / best / 1e9, 1)}), flush=True)
