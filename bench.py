@@ -499,6 +499,7 @@ def main():
         kernel_ms.append(plan.last_kernel_ms())
         pass2_ms.append(plan.last_second_pass_ms())
     sync()
+    spill_voxels = plan.last_spill_count()
     dt = time.perf_counter() - t0
     multi = None
     if world > 1:
@@ -572,7 +573,7 @@ def main():
             "dict_build_ms": dict_build_ms,
             "roofline": {"bound": "hbm", "kernel": "fit_kernel<%s>" % method, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "bytes_per_voxel": bpv, "counters": pmc_note,
+                         "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "spill_voxels": spill_voxels, "bytes_per_voxel": bpv, "counters": pmc_note,
                          "note": "fp64 VALU-issue-bound active-set iteration, not HBM-bound (DESIGN.md section 6)"},
         }
         if multi:

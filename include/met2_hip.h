@@ -323,12 +323,15 @@ int met2_metrics(met2_plan *plan, int64_t nvox, const double *fsol, const uint8_
 /* Duration in ms of the solver kernel of the most recent met2_fit / met2_fa_bruteforce on
  * this plan, measured with HIP events on the launch stream (blocks until it finished). */
 int met2_plan_last_kernel_ms(met2_plan *plan, double *ms);
-/* NNLS/T2SPARC/X2/L-curve/GCV fits run in two passes: the solver kernel with a reduced passive-set capacity (the
- * largest that lets 16 waves share a CU's LDS, never below 0.6 n_t2: 50 at n_t2 = 60; at two bins per lane the largest that
- * lets the 8 waves those kernels are compiled for share it: 71 at n_t2 = 120 -- more resident waves per CU), then the same
- * kernel at full capacity (GCV at two bins per lane: at capacity 116 first, then full) for the voxels that hit the cap (~1 %).
- * met2_plan_last_kernel_ms times the first (dominant) launch; this gives the second pass (requeue + launch),
- * 0 when there was none. */
+/* NNLS/T2SPARC/X2/L-curve/GCV fits (and BayesReg at n_t2 > 64) give every wave an LDS region for a Cholesky factor of a reduced
+ * passive-set capacity (the largest that lets 16 waves share a CU's LDS, never below 0.6 n_t2: 50 at n_t2 = 60; at two bins per
+ * lane the largest that lets the 8 waves those kernels are compiled for share it: 71 at n_t2 = 120).  A voxel whose set outgrows
+ * it (~1 % at 32 x 60, 5-10 % at 48 x 120) goes on in place with the factor's columns beyond the capacity in a per-wave slot in
+ * device memory (allocated by the first such fit on the plan: 18 MB at n_t2 = 60, 77 MB at 120): ONE solver launch per fit.
+ * met2_plan_last_spill_count: how many voxels of the most recent finished fit took that route (for reports and tests).
+ * met2_plan_last_second_pass_ms: rounds 1-4 solved those voxels again in a second launch at full capacity; that ladder runs
+ * only with MET2_TWO_PASS=1 in the environment (A/B test switch), otherwise this returns 0. */
+int met2_plan_last_spill_count(met2_plan *plan, int64_t *count);
 int met2_plan_last_second_pass_ms(met2_plan *plan, double *ms);
 
 /* Launch geometry of the solver kernel (for reports): workgroups, threads per workgroup,

@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libmet2_hip.so")
 # (-DMET2_SPLIT_TU, the shipped build: the fit kernels are instantiated in met2_fit_*.hip, one family of methods per file -- fit_kernel.hpp;
 #  with extra MET2_BUILD_DEFINES -- development builds -- met2_hip.hip instantiates them all and those files compile to nothing)
 SOURCES = ["met2_hip.hip", "met2_fit_x2_nb1.hip", "met2_fit_x2_nb2.hip", "met2_fit_x2_second.hip", "met2_fit_nnls_lcurve.hip", "met2_fit_gcv.hip", "met2_fit_bayes.hip", "met2_tv.hip", "met2_host.hip"]
-HEADERS = ["abi_common.hpp", "wave_ops.hpp", "nnls_wave.hpp", "objectives.hpp", "fit_kernel.hpp", os.path.join("..", "..", "include", "met2_hip.h")]
+HEADERS = ["abi_common.hpp", "wave_ops.hpp", "nnls_wave.hpp", "nnls_big.hpp", "objectives.hpp", "fit_kernel.hpp", os.path.join("..", "..", "include", "met2_hip.h")]
 STAMP = LIB + ".flags"          # extra compile flags the library was built with (MET2_BUILD_DEFINES, e.g. -DMET2_CYCSTATS)
 # Machine LICM off: it hoists the materialisation of fp64 literals (erf/log coefficients of the BayesReg objective, 20 register
 # pairs) and per-lane address constants out of the voxel loop, runs out of registers and spills them to scratch -- BayesReg at

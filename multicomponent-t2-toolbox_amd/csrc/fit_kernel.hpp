@@ -24,7 +24,8 @@ struct SortBufs {
     int *chunk_start;  // [nfa+1]
     int *queue;        // [1]
     int *xq;           // [8]  one queue cursor per XCD (fit kernel)
-    int *err;          // [1]  bit0: FA index out of range
+    int *err;          // [3]  [0] bit0: FA index out of range; [1], [2]: tail and head of the spill-over queue
+    int *ovf;          // [nvox] the spill-over queue: voxels whose passive set outgrew the wave's LDS region
 };
 
 // ------------------------------------------------------------------------------------------
@@ -63,6 +64,8 @@ struct FitArgs {
     int nbtab, btab_stride;
     double *chol;                         // BayesReg at two bins per lane: [grid * waves][chol_stride] scratch for the factor (chol_lean), or NULL
     int chol_stride;
+    double *big;                          // [grid * waves][big_stride]: every wave's spill-over slot for factor columns >= kmax (nnls_big.hpp), or NULL
+    int big_stride;
     double blam[MET2_BAYES_TABLE];        // the shared Brent abscissae lambda_j
 };
 
@@ -510,28 +513,354 @@ __device__ __forceinline__ void seed_load(NnlsState<NB> &st, const char *seed, i
     st.k = k;
 }
 
-// SECOND only gives the second pass of the capacity scheme its own kernel symbol (profilers then list the
-// dominant first pass and the small clean-up pass separately); the code is identical.
+// The solver calls of the voxel routine.  BIG = false (the kernel's own voxel loop): the inlined solver, as in rounds 1-4.  BIG = true (the
+// spill-over voxel routine): one NOT-inlined instance of the solver with the spill-over legs compiled in (nnls_big.hpp: big_solve_fn), the
+// state handed over through the stack -- that routine then holds the lambda search and the objectives plus calls, not nine copies of the solver.
+template <int NB, int ONE, bool BIG>
+__device__ __forceinline__ void solve_warm(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
+{
+    if constexpr (BIG) { NnlsState<NB> sc = st; big_solve_fn<NB, ONE>(S, (big_lds_dp)S.R, bd, &sc, lam, (aug ? 1 : 0) | 2); st = sc; }
+    else nnls_solve_warm<NB, ONE>(S, bd, st, lam, aug, lane);
+}
+template <int NB, int ONE, bool BIG>
+__device__ __forceinline__ void solve_cold(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
+{
+    if constexpr (BIG) { NnlsState<NB> sc = st; big_solve_fn<NB, ONE>(S, (big_lds_dp)S.R, bd, &sc, lam, aug ? 1 : 0); st = sc; }
+    else nnls_solve<NB, ONE>(S, bd, st, lam, aug, lane);
+}
+template <int NB, bool BIG>
+__device__ __forceinline__ void refine(const WaveShared &S, NnlsState<NB> &st, double lam, double bvec, int lane)
+{
+    if constexpr (BIG) { NnlsState<NB> sc = st; big_refine_fn<NB>(S, (big_lds_dp)S.R, &sc, lam, bvec); st = sc; }
+    else refine_csne<NB>(S, st, lam, bvec, lane);
+}
+
+// One voxel (motor:129-155 + motor:448-468): load, normalise, the method's lambda search, epilogue.  BIG = false: the instance in the kernel's own
+// voxel loop; a passive set that wants to outgrow the LDS capacity makes it return true, the voxel's outputs carrying MET2_ST_KOVERFLOW until the
+// spill-over kernel (or, without slots, the caller's second launch) has written them again.  BIG = true: the instance inside fit_voxel_spill, which goes on in the wave's
+// global slot (nnls_big.hpp).
+template <int METHOD, int NB, bool BIG>
+__device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S, const Band<NB> &bd, const MetricLanes<NB> &ml, int64_t v, int fa,
+                                          int seed_k, bool have_seed, int lane, int wslot)
+{
+    constexpr int ONE = (NB == 2) ? (((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE) ? 1 : MET2_ONE_REFAC) : 0;
+    const int n = A.n, m = A.m;
+    // ---- load, normalise by the first echo (motor:129-132), h = D^T b
+    double b = (lane < m) ? A.data[v * A.vs + lane * A.es] : 0.0;
+    const double km = bcast(b, 0);
+    b = b / km;
+    NnlsState<NB> st; st.itmax_hit = 0;
+    MET2_CYC_INIT(st);
+    MET2_CYC_BEGIN(c_vox);
+    nnls_reset<NB>(st);
+    project<NB>(S, b, lane, st.h);
+    double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
+
+    if (METHOD == MET2_NNLS) {
+        solve_cold<NB, ONE, BIG>(S, bd, st, 0.0, false, lane);
+    } else if (METHOD == MET2_T2SPARC) {
+        if (have_seed) { seed_load<NB>(st, A.seed, seed_k, fa, lane); solve_warm<NB, ONE, BIG>(S, bd, st, A.t2sparc_lambda, true, lane); }
+        else solve_cold<NB, ONE, BIG>(S, bd, st, A.t2sparc_lambda, true, lane);
+        regv = lamv = A.t2sparc_lambda;
+    } else if (METHOD == MET2_X2) {
+        // algorithms.py:211-233
+        solve_cold<NB, ONE, BIG>(S, bd, st, 0.0, false, lane);
+        const double SSE = sse_of<NB>(S, st, b, lane);
+        const double target = A.x2_factor * SSE;
+        int flag;
+        double last_x = -1.0, last_sse = 0.0;
+        if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);     // start of the first Brent point
+        // algorithms.py:220 solves once more at reg_opt.  The solution of the evaluation that made reg_opt Brent's best point is
+        // that solution up to rounding (the solve is deterministic and the minimiser unique): its spectrum, passive set and
+        // SSE are kept as they come by and restored at the end (85 % of the voxels of configs[1] would repeat the solve)
+        double best_x[NB], best_sse = 0.0; int best_pos[NB], best_ord[NB];
+#ifdef MET2_CYCSTATS
+        int evi = 0; double canon = 0.0;
+#endif
+#if MET2_TIE_GUARD
+        int nref = 0;
+        double lam = fminbound_tie_dev([&](double x, bool refined) {
+            if (NB == 2 && (st.itmax_hit & 2)) return 0.0;
+            if (!(refined && x == last_x)) solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
+            if (refined) refine<NB, BIG>(S, st, x, b, lane);
+            const double SSEr = sse_of<NB>(S, st, b, lane);
+            last_x = x; last_sse = SSEr;
+            return fabs(SSEr - target) / SSE;
+        }, [&]() {
+            best_sse = last_sse;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
+        }, 0.0, 10.0, A.xtol, A.maxfun, flag, nref);
+        if (MET2_TIE_GUARD == 2 && nref) stat |= 64 | (nref & 0x1f00);
+#else
+        double lam = fminbound_dev([&](double x) {
+#ifdef MET2_CYCSTATS
+            unsigned long long snap[8];
+            for (int q_ = 0; q_ < 8; ++q_) snap[q_] = st.cyc[q_];
+            const int k0_ = st.k;
+            const double gm_ = 0.5 * (3.0 - sqrt(5.0));
+            canon = (evi == 0) ? gm_ * 10.0 : (evi == 1 ? canon + gm_ * (10.0 - canon) : (evi == 2 ? gm_ * 10.0 * (1.0 - gm_) : canon * (1.0 - gm_)));
+            const bool is_canon = fabs(x - canon) <= 1e-12 * canon;
+#endif
+            if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // the passive set hit the pass's capacity: the voxel is solved again in the
+                                                            // next pass, the rest of its Brent path here costs nothing (two bins per lane,
+                                                            // where 5-10 % of the voxels do; at one bin per lane ~1 % do and the test cost
+                                                            // the X2 kernel two more spilled registers)
+            solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
+            double SSEr = sse_of<NB>(S, st, b, lane);
+#ifdef MET2_CYCSTATS
+            if (lane == 0) {
+                const int e_ = evi < 39 ? evi : 39;
+                atomicAdd(&g_ev[e_][0], 1ull);
+                for (int q_ = 1; q_ < 8; ++q_) atomicAdd(&g_ev[e_][q_], (st.cyc[q_] - snap[q_]) % 1000000000000ull);
+                atomicAdd(&g_ev[e_][8], (unsigned long long)k0_); atomicAdd(&g_ev[e_][9], (unsigned long long)st.k);
+                if (is_canon) atomicAdd(&g_ev[e_][10], 1ull);
+            }
+            ++evi;
+#endif
+            last_x = x; last_sse = SSEr;
+            return fabs(SSEr - target) / SSE;
+        }, [&]() {
+            best_sse = last_sse;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
+        }, 0.0, 10.0, A.xtol, A.maxfun, flag);
+#endif
+        if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
+        if (lam != last_x && !(NB == 2 && (st.itmax_hit & 2))) {
+            int kk = 0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                st.x[bb] = best_x[bb]; st.pos[bb] = best_pos[bb]; st.ord[bb] = best_ord[bb];
+                st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
+            }
+            st.k = kk; last_sse = best_sse;
+        }
+        regv = last_sse / SSE;                            // k_est (motor:141-143)
+        lamv = lam;
+    } else if (METHOD == MET2_LCURVE) {
+        // algorithms.py:88-113
+        // The solve at the corner (algorithms.py:111) starts from the sweep's state nearest to it: besides the last grid point
+        // the states of four evenly spaced ones are kept (iterate, and position | pivot bin packed in one word): from the last
+        // point alone the passive set had to shrink by up to ~25 bins, one plane-rotation chain each.
+        constexpr int NS = 4;
+        double le = 0.0, ln = 0.0, keep_x[NS][NB];
+        int keep_p[NS][NB];
+        for (int i = 0; i < A.nlam; ++i) {
+            double lam = A.lam_grid[i];
+            if (NB == 2 && (st.itmax_hit & 2)) break;       // capacity hit: solved again in the next pass
+            solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
+            double sse = sse_of<NB>(S, st, b, lane);
+            double sn = seminorm2<NB>(bd, st.x, n, lane);
+            if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                if (i == (q + 1) * A.nlam / (NS + 1) - 1) {
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) { keep_x[q][bb] = st.x[bb]; keep_p[q][bb] = (st.pos[bb] + 1) | (st.ord[bb] << 9); }
+                }
+        }
+        if (!(NB == 2 && (st.itmax_hit & 2))) {
+        int corner = select_corner_dev(le, ln, A.nlam, lane);
+        regv = lamv = A.lam_grid[corner];
+        {
+            int best = -1, dist = A.nlam - 1 - corner;               // the state in hand belongs to the last grid point
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int iq = (q + 1) * A.nlam / (NS + 1) - 1;
+                const int dq = abs(iq - corner);
+                if (iq >= 0 && dq < dist) { dist = dq; best = q; }
+            }
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                if (best == q) {
+                    int kk = 0;
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {
+                        st.x[bb] = keep_x[q][bb]; st.pos[bb] = (keep_p[q][bb] & 0x1ff) - 1; st.ord[bb] = keep_p[q][bb] >> 9;
+                        st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
+                    }
+                    st.k = kk;
+                }
+        }
+        solve_warm<NB, ONE, BIG>(S, bd, st, regv, true, lane);
+        }
+    } else if (METHOD == MET2_BAYESREG) {
+        // bayesian_interpolation.py:84-105
+        solve_cold<NB, 0, BIG>(S, bd, st, 0.0, false, lane);
+        int nnz = 0;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) nnz += __popcll(ballot((lane + 64 * bb < n) && (st.x[bb] > 0.0)));
+        double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
+        const double sigma = sqrt(sse_of<NB>(S, st, b, lane) / dof);
+        BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
+        int flag, ev = 0;
+        if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
+        double *cholG = (NB == 2 && A.chol) ? A.chol + (size_t)wslot * (size_t)A.chol_stride : nullptr;
+        double lam = fminbound_dev([&](double x) {
+            if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
+            solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
+            BayesTable tab{nullptr, 0.0};
+            if (A.btab && ev < A.nbtab) {                  // still on the abscissae every voxel shares?  (a rounding-level match: the table's
+                const double tl = A.blam[ev];              //  lambda_j is formed on the host, and B + lambda K does not care about an ulp)
+                if (fabs(x - tl) <= 1e-14 * tl) {
+                    const double *rec = A.btab + ((size_t)fa * A.nbtab + ev) * A.btab_stride;
+                    const double ld0 = rec[A.btab_stride - 1];
+                    if (fabs(ld0) <= 1.79769313486231570815e308) { tab.U0 = rec; tab.logdet0 = ld0; }      // (nan: the table's factorisation failed --
+                                                                                                            //  the voxel factorises itself and reports its own failure)
+                }
+            }
+            ++ev;
+            return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab, cholG);
+        }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
+        if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
+        if (bc.failed) stat |= MET2_ST_CHOLFAIL;
+        if (!(NB == 2 && (st.itmax_hit & 2))) solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
+        regv = lamv = lam;
+    } else if (METHOD == MET2_GCV || METHOD == MET2_GCV_LR) {
+        // algorithms.py:276-283
+        int flag, overflow = 0;
+        GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
+        if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
+        double lam = fminbound_dev([&](double x) {
+            if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
+            solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
+            return gcv_objective<NB, METHOD == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
+        }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
+        if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
+        if (overflow) stat |= MET2_ST_KOVERFLOW;
+        if (!(NB == 2 && (st.itmax_hit & 2))) solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
+        regv = lamv = lam;
+    }
+    if (METHOD >= 10) {
+        // objective values of method METHOD-10 on the plan's lambda grid -> fsol[v][0..nlam)
+        constexpr int BASE = METHOD - 10;
+        double SSE = 1.0; BayesCtx bc; bc.failed = 0; bc.log_detL = A.log_detL; bc.beta = 1.0;
+        if (BASE == MET2_X2 || BASE == MET2_BAYESREG) {
+            nnls_solve<NB>(S, bd, st, 0.0, false, lane);
+            SSE = sse_of<NB>(S, st, b, lane);
+            int nnz = 0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) nnz += __popcll(ballot((lane + 64 * bb < n) && (st.x[bb] > 0.0)));
+            double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
+            const double sigma = sqrt(SSE / dof);
+            bc.beta = 1.0 / (sigma * sigma);
+        }
+        double keep = 0.0; int overflow = 0;
+        GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
+        for (int i = 0; i < A.nlam; ++i) {
+            const double x = A.lam_grid[i];
+            nnls_solve<NB>(S, bd, st, x, true, lane);
+            double val;
+            if (BASE == MET2_X2) val = fabs(sse_of<NB>(S, st, b, lane) - A.x2_factor * SSE) / SSE;
+            else if (BASE == MET2_GCV || BASE == MET2_GCV_LR) val = gcv_objective<NB, BASE == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
+            else val = bayes_objective<NB>(S, bd, st, bc, x, b, lane);
+            if (lane == i) keep = val;
+        }
+        if (lane < n) A.fsol[(size_t)v * n + lane] = keep;      // nlam <= 64 values, zero-padded to n
+        if (NB == 2 && lane + 64 < n) A.fsol[(size_t)v * n + lane + 64] = 0.0;
+        if (lane == 0) { A.reg[v] = 0.0; if (A.status) A.status[v] = stat | (overflow ? MET2_ST_KOVERFLOW : 0); }
+        return false;
+    }
+    if (st.itmax_hit & 1) stat |= MET2_ST_ITMAX;
+    if (st.itmax_hit & 2) stat |= MET2_ST_KOVERFLOW;
+    MET2_CYC_END(0, c_vox);
+    MET2_CYC_FLUSH(st);
+
+    // ---- epilogue: un-normalise (motor:153-155) + metrics (motor:448-468)
+    double xs[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        xs[bb] = st.x[bb] * km;
+        if (lane + 64 * bb < n) A.fsol[(size_t)v * n + lane + 64 * bb] = xs[bb]; else xs[bb] = 0.0;
+    }
+    if (A.sig) {
+        double sg = model_signal<NB>(S, st, lane) * km;
+        if (lane < m) A.sig[(size_t)v * m + lane] = sg;
+    }
+    if (A.maps) write_metrics<NB>(ml, xs, true, A.maps, A.nvox, v, lane);
+    if (lane == 0) {
+        A.reg[v] = regv;
+        if (A.lam) A.lam[v] = lamv;
+        if (A.status) A.status[v] = stat;
+    }
+    return !BIG && (st.itmax_hit & 2) != 0;                     // the set outgrew the wave's LDS region (the outputs just written carry MET2_ST_KOVERFLOW): the caller queues the voxel for the spill-over kernel
+}
+
+// the wave's view of the plan: everything of WaveShared that does not depend on the flip angle
+__device__ __forceinline__ void fit_shared(const FitArgs &A, WaveShared &S, double *sR, int wslot)
+{
+    S.R = sR; S.n = A.n; S.m = A.m; S.kmax = A.kmax; S.rcap = A.wave_doubles; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = A.m; S.buffer_rows = true; S.reorder = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
+    S.B = A.Bfa; S.D = A.Dfa; S.bstride = A.n; S.dstride = A.n;
+    S.Rg = A.big ? A.big + (size_t)wslot * (size_t)A.big_stride : nullptr; S.gbase = col_base(A.kmax);
+}
+template <int METHOD>
+__device__ __forceinline__ void fit_shared_fa(const FitArgs &A, WaveShared &S, int fa)
+{
+    const int n = A.n, m = A.m;
+    S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
+    S.DtG = ((METHOD >= 10 ? METHOD - 10 : METHOD) == MET2_GCV_LR) ? A.Aq + (size_t)fa * n * MET2_GCV_LR_RANK : S.Dt;
+}
+
+// One queued spill-over voxel, solved from its first echo with the spill-over routines compiled in (fit_voxel<BIG = true>): the evaluations that
+// fit the LDS capacity run the fast legs as before, the others keep the factor's columns beyond it in the wave's global slot.  NOT inlined into
+// the spill-over kernel's queue loop, and everything it needs is rebuilt inside from the arguments: with the voxel routine inlined in that
+// loop, what the loop keeps across the solver calls (the plan's scalars, the penalty bands, the metric windows) did not survive a wave's first
+// voxel -- every wave faulted on its second one (round 5: 3 020 queued voxels on 2 048 waves; 1 549 ran clean).  The arguments arrive in
+// vector registers and the plan's arguments through a private copy: everything wave-uniform is made scalar again (readfirstlane).
+template <int METHOD, int NB>
+__device__ __attribute__((noinline)) void fit_voxel_spill(const FitArgs *Ap, big_lds_dp sRl, int64_t v, int fa, int wslot)
+{
+    const int lane = big_lane();
+    double *sR = (double *)sRl;
+    FitArgs A;
+    {
+        static_assert(sizeof(FitArgs) % 4 == 0, "FitArgs is copied word by word");
+        const int *src = (const int *)Ap;
+        int *dst = (int *)&A;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(FitArgs) / 4); ++i) dst[i] = big_rfl(src[i]);
+    }
+    v = (int64_t)big_rfl((u64)v); fa = big_rfl(fa); wslot = big_rfl(wslot);
+    WaveShared S;
+    fit_shared(A, S, sR, wslot);
+    fit_shared_fa<METHOD>(A, S, fa);
+    Band<NB> bd;
+    load_band<NB>(bd, A.kband, A.lband, lane);
+    MetricLanes<NB> ml;
+    metric_lanes<NB>(ml, A.t2s, A.n, A.cut_m, A.cut_ie, lane);
+    const int seed_k = (MET2_SEED && A.seed) ? ((const SeedRec *)A.seed)[fa].k : 0;
+    const bool have_seed = seed_k > 0 && seed_k <= A.kmax;
+    (void)fit_voxel<METHOD, NB, true>(A, S, bd, ml, v, fa, seed_k, have_seed, lane, wslot);
+}
+
+// SECOND = false: the fit kernel proper.  Every wave pulls voxels from the FA-sorted queue; a voxel whose passive set outgrows the wave's LDS region
+// (capacity A.kmax: as many resident waves as the registers allow) is put on the spill-over queue, nothing written.
+// SECOND = true: the spill-over kernel, launched behind it with the same geometry: the same voxel routine with BIG = true -- the solver with the
+// spill-over legs compiled in (nnls_big.hpp), one not-inlined instance -- on the queued voxels, at the first kernel's occupancy (8 waves per CU at
+// nT2 = 120 where the full-size factor of rounds 1-4's clean-up pass allowed 2) and without the re-sort (five small kernels) that pass needed.
+// Why a second kernel and not a call behind (or inside) the first one's voxel loop: a kernel that contains a call keeps registers for the calling
+// convention throughout -- fit_kernel<X2, 1> went from 29 spill stores / 47 reloads to 52 / 160 and configs[1] from 150.4 to 157.5 ms with the
+// call BEHIND the loop (inside it: 7 000 reloads); and with the spill-over legs inlined into the nine copies of the solver the X2 kernel holds,
+// one translation unit compiles for six minutes.  The voxels wait for the first kernel's last wave either way.
 template <int METHOD, int NB, bool SECOND>
 __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(FitArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int n = A.n, m = A.m, kmax = A.kmax;
-    // one position slot while k <= 64 (nnls_wave.hpp: MET2_ONE_SLOT) in the two-bins-per-lane kernels that have the registers for a second
-    // code path: NNLS, T2SPARC, X2, L-curve (ONE = 1); GCV and BayesReg take it for the re-factorisation and the back substitution (ONE = 3)
-    constexpr int ONE = (NB == 2) ? (((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE) ? 1 : MET2_ONE_REFAC) : 0;
     const int tri = A.wave_doubles;
     double *sR = smem + (size_t)wave * tri;             // every wave's region starts 16-byte aligned
 
+    const int wslot = (int)(blockIdx.x * (unsigned)A.waves + (unsigned)wave);      // this wave's slot in the per-wave scratch arrays
     WaveShared S;
-    S.R = sR; S.n = n; S.m = m; S.kmax = kmax; S.rcap = tri; S.K = A.Kd; S.kband = A.kband; S.Dt = nullptr; S.DtG = A.Dtfa; S.dtstride = m; S.buffer_rows = true; S.reorder = true; S.have_bdiag = false; S.bdiag[0] = S.bdiag[1] = 0.0;
-    S.B = A.Bfa; S.D = A.Dfa; S.bstride = n; S.dstride = n;
+    fit_shared(A, S, sR, wslot);
     Band<NB> bd;
     load_band<NB>(bd, A.kband, A.lband, lane);
     MetricLanes<NB> ml;
     metric_lanes<NB>(ml, A.t2s, n, A.cut_m, A.cut_ie, lane);
 
+    if constexpr (!SECOND) {
     const int nchunks = A.sb.chunk_start[A.nfa];
     for (int round = 0; round <= nchunks; ++round) {      // the queue hands out each chunk once
         // every WAVE pulls its own (small) chunk from the global queue -- no workgroup barrier anywhere, so a wave never
@@ -558,254 +887,48 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
         const int fa = lo;
         const int first = A.sb.bucket_start[fa] + (c - A.sb.chunk_start[fa]) * A.chunk;
         const int cnt = min(A.chunk, A.sb.bucket_start[fa + 1] - first);
-        S.B = A.Bfa + (size_t)fa * n * n; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
-        S.DtG = ((METHOD >= 10 ? METHOD - 10 : METHOD) == MET2_GCV_LR) ? A.Aq + (size_t)fa * n * MET2_GCV_LR_RANK : S.Dt;
+        fit_shared_fa<METHOD>(A, S, fa);
         const int seed_k = (MET2_SEED && A.seed) ? ((const SeedRec *)A.seed)[fa].k : 0;
         const bool have_seed = seed_k > 0 && seed_k <= kmax;
         for (int slot = 0; slot < cnt; ++slot) {
             MET2_STAT(4, slot);
             const int64_t v = A.sb.perm[first + slot];
 
-            // ---- load, normalise by the first echo (motor:129-132), h = D^T b
-            double b = (lane < m) ? A.data[v * A.vs + lane * A.es] : 0.0;
-            const double km = bcast(b, 0);
-            b = b / km;
-            NnlsState<NB> st; st.itmax_hit = 0;
-            MET2_CYC_INIT(st);
-            MET2_CYC_BEGIN(c_vox);
-            nnls_reset<NB>(st);
-            project<NB>(S, b, lane, st.h);
-            double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
-
-            if (METHOD == MET2_NNLS) {
-                nnls_solve<NB, ONE>(S, bd, st, 0.0, false, lane);
-            } else if (METHOD == MET2_T2SPARC) {
-                if (have_seed) { seed_load<NB>(st, A.seed, seed_k, fa, lane); nnls_solve_warm<NB, ONE>(S, bd, st, A.t2sparc_lambda, true, lane); }
-                else nnls_solve<NB, ONE>(S, bd, st, A.t2sparc_lambda, true, lane);
-                regv = lamv = A.t2sparc_lambda;
-            } else if (METHOD == MET2_X2) {
-                // algorithms.py:211-233
-                nnls_solve<NB, ONE>(S, bd, st, 0.0, false, lane);
-                const double SSE = sse_of<NB>(S, st, b, lane);
-                const double target = A.x2_factor * SSE;
-                int flag;
-                double last_x = -1.0, last_sse = 0.0;
-                if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);     // start of the first Brent point
-                // algorithms.py:220 solves once more at reg_opt.  The solution of the evaluation that made reg_opt Brent's best point is
-                // that solution up to rounding (the solve is deterministic and the minimiser unique): its spectrum, passive set and
-                // SSE are kept as they come by and restored at the end (85 % of the voxels of configs[1] would repeat the solve)
-                double best_x[NB], best_sse = 0.0; int best_pos[NB], best_ord[NB];
-#ifdef MET2_CYCSTATS
-                int evi = 0; double canon = 0.0;
-#endif
-#if MET2_TIE_GUARD
-                int nref = 0;
-                double lam = fminbound_tie_dev([&](double x, bool refined) {
-                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;
-                    if (!(refined && x == last_x)) nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
-                    if (refined) refine_csne<NB>(S, st, x, b, lane);
-                    const double SSEr = sse_of<NB>(S, st, b, lane);
-                    last_x = x; last_sse = SSEr;
-                    return fabs(SSEr - target) / SSE;
-                }, [&]() {
-                    best_sse = last_sse;
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
-                }, 0.0, 10.0, A.xtol, A.maxfun, flag, nref);
-                if (MET2_TIE_GUARD == 2 && nref) stat |= 64 | (nref & 0x1f00);
-#else
-                double lam = fminbound_dev([&](double x) {
-#ifdef MET2_CYCSTATS
-                    unsigned long long snap[8];
-                    for (int q_ = 0; q_ < 8; ++q_) snap[q_] = st.cyc[q_];
-                    const int k0_ = st.k;
-                    const double gm_ = 0.5 * (3.0 - sqrt(5.0));
-                    canon = (evi == 0) ? gm_ * 10.0 : (evi == 1 ? canon + gm_ * (10.0 - canon) : (evi == 2 ? gm_ * 10.0 * (1.0 - gm_) : canon * (1.0 - gm_)));
-                    const bool is_canon = fabs(x - canon) <= 1e-12 * canon;
-#endif
-                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // the passive set hit the pass's capacity: the voxel is solved again in the
-                                                                    // next pass, the rest of its Brent path here costs nothing (two bins per lane,
-                                                                    // where 5-10 % of the voxels do; at one bin per lane ~1 % do and the test cost
-                                                                    // the X2 kernel two more spilled registers)
-                    nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
-                    double SSEr = sse_of<NB>(S, st, b, lane);
-#ifdef MET2_CYCSTATS
-                    if (lane == 0) {
-                        const int e_ = evi < 39 ? evi : 39;
-                        atomicAdd(&g_ev[e_][0], 1ull);
-                        for (int q_ = 1; q_ < 8; ++q_) atomicAdd(&g_ev[e_][q_], (st.cyc[q_] - snap[q_]) % 1000000000000ull);
-                        atomicAdd(&g_ev[e_][8], (unsigned long long)k0_); atomicAdd(&g_ev[e_][9], (unsigned long long)st.k);
-                        if (is_canon) atomicAdd(&g_ev[e_][10], 1ull);
-                    }
-                    ++evi;
-#endif
-                    last_x = x; last_sse = SSEr;
-                    return fabs(SSEr - target) / SSE;
-                }, [&]() {
-                    best_sse = last_sse;
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
-                }, 0.0, 10.0, A.xtol, A.maxfun, flag);
-#endif
-                if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                if (lam != last_x && !(NB == 2 && (st.itmax_hit & 2))) {
-                    int kk = 0;
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) {
-                        st.x[bb] = best_x[bb]; st.pos[bb] = best_pos[bb]; st.ord[bb] = best_ord[bb];
-                        st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
-                    }
-                    st.k = kk; last_sse = best_sse;
-                }
-                regv = last_sse / SSE;                            // k_est (motor:141-143)
-                lamv = lam;
-            } else if (METHOD == MET2_LCURVE) {
-                // algorithms.py:88-113
-                // The solve at the corner (algorithms.py:111) starts from the sweep's state nearest to it: besides the last grid point
-                // the states of four evenly spaced ones are kept (iterate, and position | pivot bin packed in one word): from the last
-                // point alone the passive set had to shrink by up to ~25 bins, one plane-rotation chain each.
-                constexpr int NS = 4;
-                double le = 0.0, ln = 0.0, keep_x[NS][NB];
-                int keep_p[NS][NB];
-                for (int i = 0; i < A.nlam; ++i) {
-                    double lam = A.lam_grid[i];
-                    if (NB == 2 && (st.itmax_hit & 2)) break;       // capacity hit: solved again in the next pass
-                    nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
-                    double sse = sse_of<NB>(S, st, b, lane);
-                    double sn = seminorm2<NB>(bd, st.x, n, lane);
-                    if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
-#pragma unroll
-                    for (int q = 0; q < NS; ++q)
-                        if (i == (q + 1) * A.nlam / (NS + 1) - 1) {
-#pragma unroll
-                            for (int bb = 0; bb < NB; ++bb) { keep_x[q][bb] = st.x[bb]; keep_p[q][bb] = (st.pos[bb] + 1) | (st.ord[bb] << 9); }
-                        }
-                }
-                if (!(NB == 2 && (st.itmax_hit & 2))) {
-                int corner = select_corner_dev(le, ln, A.nlam, lane);
-                regv = lamv = A.lam_grid[corner];
-                {
-                    int best = -1, dist = A.nlam - 1 - corner;               // the state in hand belongs to the last grid point
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        const int iq = (q + 1) * A.nlam / (NS + 1) - 1;
-                        const int dq = abs(iq - corner);
-                        if (iq >= 0 && dq < dist) { dist = dq; best = q; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < NS; ++q)
-                        if (best == q) {
-                            int kk = 0;
-#pragma unroll
-                            for (int bb = 0; bb < NB; ++bb) {
-                                st.x[bb] = keep_x[q][bb]; st.pos[bb] = (keep_p[q][bb] & 0x1ff) - 1; st.ord[bb] = keep_p[q][bb] >> 9;
-                                st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
-                            }
-                            st.k = kk;
-                        }
-                }
-                nnls_solve_warm<NB, ONE>(S, bd, st, regv, true, lane);
-                }
-            } else if (METHOD == MET2_BAYESREG) {
-                // bayesian_interpolation.py:84-105
-                nnls_solve<NB>(S, bd, st, 0.0, false, lane);
-                int nnz = 0;
-#pragma unroll
-                for (int bb = 0; bb < NB; ++bb) nnz += __popcll(ballot((lane + 64 * bb < n) && (st.x[bb] > 0.0)));
-                double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
-                const double sigma = sqrt(sse_of<NB>(S, st, b, lane) / dof);
-                BayesCtx bc; bc.beta = 1.0 / (sigma * sigma); bc.log_detL = A.log_detL; bc.failed = 0;
-                int flag, ev = 0;
-                if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
-                double *cholG = (NB == 2 && A.chol) ? A.chol + (size_t)(blockIdx.x * (unsigned)A.waves + (unsigned)wave) * (size_t)A.chol_stride : nullptr;
-                double lam = fminbound_dev([&](double x) {
-                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
-                    nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
-                    BayesTable tab{nullptr, 0.0};
-                    if (A.btab && ev < A.nbtab) {                  // still on the abscissae every voxel shares?  (a rounding-level match: the table's
-                        const double tl = A.blam[ev];              //  lambda_j is formed on the host, and B + lambda K does not care about an ulp)
-                        if (fabs(x - tl) <= 1e-14 * tl) {
-                            const double *rec = A.btab + ((size_t)fa * A.nbtab + ev) * A.btab_stride;
-                            const double ld0 = rec[A.btab_stride - 1];
-                            if (fabs(ld0) <= 1.79769313486231570815e308) { tab.U0 = rec; tab.logdet0 = ld0; }      // (nan: the table's factorisation failed --
-                                                                                                                    //  the voxel factorises itself and reports its own failure)
-                        }
-                    }
-                    ++ev;
-                    return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab, cholG);
-                }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
-                if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                if (bc.failed) stat |= MET2_ST_CHOLFAIL;
-                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
-                regv = lamv = lam;
-            } else if (METHOD == MET2_GCV || METHOD == MET2_GCV_LR) {
-                // algorithms.py:276-283
-                int flag, overflow = 0;
-                GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
-                if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
-                double lam = fminbound_dev([&](double x) {
-                    if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
-                    nnls_solve_warm<NB, ONE>(S, bd, st, x, true, lane);
-                    return gcv_objective<NB, METHOD == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
-                }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
-                if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
-                if (overflow) stat |= MET2_ST_KOVERFLOW;
-                if (!(NB == 2 && (st.itmax_hit & 2))) nnls_solve_warm<NB, ONE>(S, bd, st, lam, true, lane);
-                regv = lamv = lam;
-            }
-            if (METHOD >= 10) {
-                // objective values of method METHOD-10 on the plan's lambda grid -> fsol[v][0..nlam)
-                constexpr int BASE = METHOD - 10;
-                double SSE = 1.0; BayesCtx bc; bc.failed = 0; bc.log_detL = A.log_detL; bc.beta = 1.0;
-                if (BASE == MET2_X2 || BASE == MET2_BAYESREG) {
-                    nnls_solve<NB>(S, bd, st, 0.0, false, lane);
-                    SSE = sse_of<NB>(S, st, b, lane);
-                    int nnz = 0;
-#pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) nnz += __popcll(ballot((lane + 64 * bb < n) && (st.x[bb] > 0.0)));
-                    double dof = (double)(m - nnz); dof = dof < 1.0 ? 1.0 : dof;
-                    const double sigma = sqrt(SSE / dof);
-                    bc.beta = 1.0 / (sigma * sigma);
-                }
-                double keep = 0.0; int overflow = 0;
-                GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
-                for (int i = 0; i < A.nlam; ++i) {
-                    const double x = A.lam_grid[i];
-                    nnls_solve<NB>(S, bd, st, x, true, lane);
-                    double val;
-                    if (BASE == MET2_X2) val = fabs(sse_of<NB>(S, st, b, lane) - A.x2_factor * SSE) / SSE;
-                    else if (BASE == MET2_GCV || BASE == MET2_GCV_LR) val = gcv_objective<NB, BASE == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
-                    else val = bayes_objective<NB>(S, bd, st, bc, x, b, lane);
-                    if (lane == i) keep = val;
-                }
-                if (lane < n) A.fsol[(size_t)v * n + lane] = keep;      // nlam <= 64 values, zero-padded to n
-                if (NB == 2 && lane + 64 < n) A.fsol[(size_t)v * n + lane + 64] = 0.0;
-                if (lane == 0) { A.reg[v] = 0.0; if (A.status) A.status[v] = stat | (overflow ? MET2_ST_KOVERFLOW : 0); }
-                continue;
-            }
-            if (st.itmax_hit & 1) stat |= MET2_ST_ITMAX;
-            if (st.itmax_hit & 2) stat |= MET2_ST_KOVERFLOW;
-            MET2_CYC_END(0, c_vox);
-            MET2_CYC_FLUSH(st);
-
-            // ---- epilogue: un-normalise (motor:153-155) + metrics (motor:448-468)
-            double xs[NB];
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb) {
-                xs[bb] = st.x[bb] * km;
-                if (lane + 64 * bb < n) A.fsol[(size_t)v * n + lane + 64 * bb] = xs[bb]; else xs[bb] = 0.0;
-            }
-            if (A.sig) {
-                double sg = model_signal<NB>(S, st, lane) * km;
-                if (lane < m) A.sig[(size_t)v * m + lane] = sg;
-            }
-            if (A.maps) write_metrics<NB>(ml, xs, true, A.maps, A.nvox, v, lane);
-            if (lane == 0) {
-                A.reg[v] = regv;
-                if (A.lam) A.lam[v] = lamv;
-                if (A.status) A.status[v] = stat;
+            if (fit_voxel<METHOD, NB, false>(A, S, bd, ml, v, fa, seed_k, have_seed, lane, wslot) && A.big) {
+                // the set outgrew the wave's LDS region: the voxel goes to the spill-over queue
+                if (lane == 0) A.sb.ovf[atomicAdd(A.sb.err + 1, 1)] = (int)v;
             }
         }
+    }
+    } else {
+    // ---- the spill-over queue (written by the launch before this one): every wave takes entries until none is left
+    if constexpr (METHOD < 10) {
+    const int ntail = A.sb.err[1];
+    FitArgs Ac = A;                                       // (a private copy for the not-inlined voxel routine)
+    // The workgroup's LDS is carved for as few waves as give every queued voxel a wave of its own (this kernel's duration is the latency of its
+    // slowest voxel when the queue is short, its throughput when it is long): w2 waves, each with the largest factor capacity its share holds --
+    // at nT2 = 120: 8 waves at capacity 71 (the first kernel's), 7 / 75, 6 / 81, 5 / 89, 4 / 100, 3 / 116, 2 and 1 at 120 (no spill-over leg runs);
+    // at nT2 = 60: 16 / 50 ... 11 and fewer at 60.  The other waves leave at once.
+    {
+        const int total = A.waves * A.wave_doubles, wgs = (int)gridDim.x;
+        int w2 = A.waves;
+        while (w2 > 1 && (int64_t)(w2 - 1) * wgs >= ntail) --w2;
+        const int per = (total / w2) & ~1;
+        int k2 = A.kmax;
+        while (k2 < n && col_base(k2 + 1) <= per) ++k2;
+        if (wave >= w2) return;
+        Ac.kmax = k2; Ac.wave_doubles = per;
+        sR = smem + (size_t)wave * per;
+    }
+    for (;;) {
+        int i = ntail;
+        if (lane == 0) i = atomicAdd(A.sb.err + 2, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= ntail) break;
+        const int64_t v = A.sb.ovf[i];
+        fit_voxel_spill<METHOD, NB>(&Ac, (big_lds_dp)sR, v, A.sb.key[v], wslot);
+    }
+    }
     }
 }
 

@@ -5,4 +5,6 @@ template int launch_fit_nb<5, 1, false>(const FitArgs &, const LaunchGeom &, hip
 template int launch_fit_nb<5, 2, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
 template int launch_fit_nb<15, 1, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
 template int launch_fit_nb<15, 2, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<5, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<5, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
 #endif

@@ -9,4 +9,8 @@ template int launch_fit_nb<14, 1, false>(const FitArgs &, const LaunchGeom &, hi
 template int launch_fit_nb<14, 2, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
 template int launch_fit_nb<16, 1, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
 template int launch_fit_nb<16, 2, false>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<4, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<4, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<6, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+template int launch_fit_nb<6, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
 #endif

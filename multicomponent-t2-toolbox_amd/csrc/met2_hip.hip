@@ -66,6 +66,12 @@ extern template int launch_fit_nb<2, 1, true>(const FitArgs &, const LaunchGeom 
 extern template int launch_fit_nb<2, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
 extern template int launch_fit_nb<3, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
 extern template int launch_fit_nb<3, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+extern template int launch_fit_nb<4, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+extern template int launch_fit_nb<4, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+extern template int launch_fit_nb<5, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+extern template int launch_fit_nb<5, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+extern template int launch_fit_nb<6, 1, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
+extern template int launch_fit_nb<6, 2, true>(const FitArgs &, const LaunchGeom &, hipStream_t);
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -987,7 +993,7 @@ struct met2_plan {
     double log_detL = 0.0;      // log(det(L)) as bayesian_interpolation.py:100,123 uses it (-inf for L2)
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
-    int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr;
+    int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr, *dOvf = nullptr;
     char *dSeed = nullptr;                                // seed_kernel's output: [3][nfa] SeedRec
     bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
     bool seeds_ok = false;                                // B + lambda K is positive definite at the seed lambdas (checked on the host for
@@ -999,8 +1005,10 @@ struct met2_plan {
     double gcv_res = 0.0;                                 // the largest of dAqRes
     bool gcv_lr = false;                                  // every flip angle's dictionary is of numerical rank <= 16: the GCV trace takes the 17 x 17 form
     double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
+    double *dBig = nullptr; int64_t cap_big = 0;          // the waves' spill-over slots: factor columns beyond the LDS capacity (nnls_big.hpp), grown on demand
+    int last_spill = 0;                                   // voxels of the last finished fit(s) that used them
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
-    int *hErr = nullptr;                                  // pinned: the FA-range error word of an enqueued fit lands here
+    int *hErr = nullptr;                                  // pinned [2]: the FA-range error word of an enqueued fit lands here, and its spill-over count
     bool err_pending = false;
     hipStream_t err_stream = nullptr;                     // the stream the fits since the last finish were enqueued on (one plan serves one stream at a time)
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
@@ -1041,8 +1049,10 @@ static int ensure_sort_bufs(met2_plan *p, int64_t nvox)
     if (nvox <= p->cap_vox) return MET2_OK;
     if (p->dKey) HIPCHK(hipFree(p->dKey));
     if (p->dPerm) HIPCHK(hipFree(p->dPerm));
+    if (p->dOvf) HIPCHK(hipFree(p->dOvf));
     HIPCHK(hipMalloc(&p->dKey, sizeof(int) * (size_t)nvox));
     HIPCHK(hipMalloc(&p->dPerm, sizeof(int) * (size_t)nvox));
+    HIPCHK(hipMalloc(&p->dOvf, sizeof(int) * (size_t)nvox));
     p->cap_vox = nvox;
     return MET2_OK;
 }
@@ -1051,7 +1061,7 @@ static SortBufs sort_bufs(met2_plan *p)
 {
     SortBufs sb;
     const int nf = p->n_fa + 1;
-    sb.key = p->dKey; sb.perm = p->dPerm;
+    sb.key = p->dKey; sb.perm = p->dPerm; sb.ovf = p->dOvf;
     sb.hist = p->dSmall; sb.cursor = p->dSmall + nf; sb.bucket_start = p->dSmall + 2 * nf; sb.chunk_start = p->dSmall + 3 * nf;
     sb.queue = p->dSmall + 4 * nf; sb.err = p->dSmall + 4 * nf + 1; sb.xq = p->dSmall + 4 * nf + 8;
     return sb;
@@ -1156,9 +1166,9 @@ static int mid_kmax(const met2_plan *p, int method, int kfast)
 template <int METHOD>
 static int launch_fit(const FitArgs &A, const LaunchGeom &g, hipStream_t s, bool second = false)
 {
-    if (second) {      // only the capacity-scheme methods have a second pass
-        if (METHOD > MET2_LCURVE) return fail(MET2_E_INVALID, "no second pass for this method");
-        constexpr int M2 = METHOD > MET2_LCURVE ? MET2_NNLS : METHOD;
+    if (second) {      // the spill-over kernel (fit_kernel.hpp): every method but the objective grids
+        if (METHOD >= 10) return fail(MET2_E_INVALID, "no spill-over kernel for this method");
+        constexpr int M2 = METHOD >= 10 ? MET2_NNLS : METHOD;
         return g.nb == 2 ? launch_fit_nb<M2, 2, true>(A, g, s) : launch_fit_nb<M2, 1, true>(A, g, s);
     }
     return g.nb == 2 ? launch_fit_nb<METHOD, 2, false>(A, g, s) : launch_fit_nb<METHOD, 1, false>(A, g, s);
@@ -1181,13 +1191,13 @@ static int launch_method(int method, const FitArgs &A, const LaunchGeom &g, hipS
 #endif
 #if MET2_HAS(4)
     case 10 + MET2_GCV: return launch_fit<10 + MET2_GCV>(A, g, s);
-    case MET2_GCV: return launch_fit<MET2_GCV>(A, g, s);      // its clean-up pass runs the same kernel symbol
+    case MET2_GCV: return launch_fit<MET2_GCV>(A, g, s, second);
     case 10 + MET2_GCV_LR: return launch_fit<10 + MET2_GCV_LR>(A, g, s);
-    case MET2_GCV_LR: return launch_fit<MET2_GCV_LR>(A, g, s);
+    case MET2_GCV_LR: return launch_fit<MET2_GCV_LR>(A, g, s, second);
 #endif
 #if MET2_HAS(5)
     case 10 + MET2_BAYESREG: return launch_fit<10 + MET2_BAYESREG>(A, g, s);
-    case MET2_BAYESREG: return launch_fit<MET2_BAYESREG>(A, g, s);
+    case MET2_BAYESREG: return launch_fit<MET2_BAYESREG>(A, g, s, second);
 #endif
     case MET2_NNLS: return launch_fit<MET2_NNLS>(A, g, s, second);
 #if MET2_HAS(1)
@@ -1513,8 +1523,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
     HIPCHK(hipMalloc(&p->dSeed, sizeof(SeedRec) * 3 * (size_t)n_fa));
-    HIPCHK(hipHostMalloc((void **)&p->hErr, sizeof(int), hipHostMallocDefault));
-    *p->hErr = 0;
+    HIPCHK(hipHostMalloc((void **)&p->hErr, 2 * sizeof(int), hipHostMallocDefault));
+    p->hErr[0] = p->hErr[1] = 0;
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1554,7 +1564,7 @@ int met2_plan_destroy(met2_plan *p)
     if (!p) return MET2_OK;
     met2::host_release(p);           // what met2_fit_host keeps with the plan (met2_host.hip)
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dQt, p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol};
+    void *bufs[] = {p->dQt, p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dOvf, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol, p->dBig};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1769,8 +1779,9 @@ int met2_plan_finish(met2_plan *p, void *stream)
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (p->err_pending) {
         p->err_pending = false;
-        const int herr = *p->hErr;
-        *p->hErr = 0;
+        const int herr = p->hErr[0];
+        p->last_spill = p->hErr[1];
+        p->hErr[0] = 0;
         if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
     }
     return MET2_OK;
@@ -1809,7 +1820,8 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     rc = fit_geometry(p, objgrid ? kmeth + 10 : kmeth, g, kfast, 0, nvox);
     if (rc) return rc;
     if (kfast) { rc = fit_geometry(p, kmeth, g2, 0, 0, nvox); if (rc) return rc; }
-    if (kfast && !status) {        // the second pass is driven by the status words
+    const bool two_pass = getenv("MET2_TWO_PASS") != nullptr;      // test switch (A/B): the two-launch capacity ladder of rounds 1-4 instead of the spill-over slots
+    if (kfast && two_pass && !status) {        // the second pass is driven by the status words
         if (p->cap_status < nvox) {
             if (p->dStatus) HIPCHK(hipFree(p->dStatus));
             HIPCHK(hipMalloc(&p->dStatus, sizeof(int32_t) * (size_t)nvox));
@@ -1886,6 +1898,23 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
         }
         A.chol = p->dChol; A.chol_stride = stride;
     }
+    // spill-over slots (nnls_big.hpp): a set that outgrows the LDS capacity of the launch goes on in place, its columns beyond the capacity in
+    // the wave's slot -- one launch per fit.
+    A.big = nullptr; A.big_stride = 0;
+    if (kfast && !two_pass) {
+        const int stride = (col_base(p->n_t2) - col_base(g.kmax) + 15) & ~15;
+        LaunchGeom gw;                                                      // sized for the widest launch of this shape (a short voxel list runs fewer waves):
+        rc = fit_geometry(p, kmeth, gw, kfast, 0, -1);                      // the slots are allocated once, not per block of a host pipeline
+        if (rc) return rc;
+        const int64_t need = (int64_t)gw.grid * gw.waves * stride;
+        if (p->cap_big < need) {
+            if (p->dBig) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(p->dBig)); p->dBig = nullptr; p->cap_big = 0; }
+            HIPCHK(hipMalloc(&p->dBig, sizeof(double) * (size_t)need));
+            p->cap_big = need;
+        }
+        A.big = p->dBig; A.big_stride = stride;
+    }
+    const bool ladder = kfast && !A.big;
     for (int j = 0; j < (MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1); ++j) A.blam[j] = p->blam[j];
     if (MET2_BAYES_TABLE > 0 && method == MET2_BAYESREG && !objgrid && p->dBtab && p->seeds_valid && p->seeds_ok && !tuning_env("MET2_NO_BAYES_TABLE", 0, 1, 0)) {
         A.btab = p->dBtab; A.nbtab = MET2_BAYES_TABLE;
@@ -1895,7 +1924,14 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     rc = launch_method(objgrid ? kmeth + 10 : kmeth, A, g, s);
     if (rc) return rc;
     HIPCHK(hipEventRecord(p->ev1, s));
-    if (kfast) {
+    if (A.big) {
+        // the spill-over kernel: the voxels the first kernel queued (their passive set outgrew the LDS capacity), same geometry, the solver with its
+        // spill-over legs -- no re-sort, no second capacity; it finds an empty queue in most launches at one bin per lane
+        rc = launch_method(kmeth, A, g, s, true);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(p->ev2, s));
+        p->timed2 = true;
+    } else if (ladder) {
         // gated-out voxels are finalised from the first pass's keys, then the key/perm buffers are reused
         hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
                            sig, reg, lam, maps);
@@ -1911,7 +1947,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
             rc = fit_geometry(p, kmeth, gm, kmid, 0, -1);
             if (rc) return rc;
             A2.kmax = gm.kmax; A2.waves = gm.waves; A2.wave_doubles = gm.wave_doubles;
-            rc = launch_method(kmeth, A2, gm, s, true);
+            rc = launch_method(kmeth, A2, gm, s);
             if (rc) return rc;
             hipLaunchKernelGGL(reset_sort_kernel, dim3(1), dim3(256), 0, s, sb, p->n_fa, 1);
             hipLaunchKernelGGL(requeue_overflow_kernel, dim3(nb), dim3(256), 0, s, nvox, fa_index, status, sb);
@@ -1920,7 +1956,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
             HIPCHK(hipGetLastError());
         }
         A2.kmax = g2.kmax; A2.waves = g2.waves; A2.wave_doubles = g2.wave_doubles;
-        rc = launch_method(kmeth, A2, g2, s, true);
+        rc = launch_method(kmeth, A2, g2, s);
         if (rc) return rc;
         HIPCHK(hipEventRecord(p->ev2, s));
         p->timed2 = true;
@@ -1947,6 +1983,11 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
             }
         }
 #endif
+#ifdef MET2_BIGSTATS
+        { unsigned long long bs[16]; HIPCHK(hipMemcpyFromSymbol(bs, HIP_SYMBOL(met2::g_bigstats), sizeof(bs)));
+          fprintf(stderr, "[met2] spill-over voxels: solver calls=%llu, with spill-over legs=%llu | cycles plain=%llu spill=%llu (refactor in slot %llu) | appends=%llu removals=%llu refactors=%llu | k start sum=%llu end sum=%llu\n",
+                  bs[0], bs[1], bs[2], bs[3], bs[9], bs[4], bs[5], bs[6], bs[8], bs[7]); }
+#endif
 #ifdef MET2_LOOPSTATS
         int ls[8];
         HIPCHK(hipMemcpyFromSymbol(ls, HIP_SYMBOL(met2::g_loopstats), sizeof(ls)));
@@ -1954,14 +1995,14 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
 #endif
         fflush(stderr);
     }
-    if (!kfast) {
+    if (!ladder) {
         hipLaunchKernelGGL(finalize_unfitted_kernel, dim3(p->cus * 4), dim3(256), 0, s, nvox, p->n_t2, p->n_te, p->dKey, mask, fsol,
                            objgrid ? nullptr : sig, reg, objgrid ? nullptr : lam, objgrid ? nullptr : maps);
         HIPCHK(hipGetLastError());
     }
     // FA index range errors (IndexError in the reference): the error word lands in the plan's pinned host word; the blocking entries
     // wait for it here, an enqueued fit leaves it to met2_plan_finish (errors of several enqueued fits accumulate: the kernel ORs)
-    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));      // the error word and the spill-over count (the queue's tail)
     p->err_pending = true; p->err_stream = s;
     if (!sync) return MET2_OK;
     return met2_plan_finish(p, stream);
@@ -2147,6 +2188,13 @@ int met2_plan_last_kernel_ms(met2_plan *p, double *ms)
     float f = 0.f;
     HIPCHK(hipEventElapsedTime(&f, p->ev0, p->ev1));
     *ms = (double)f;
+    return MET2_OK;
+}
+
+int met2_plan_last_spill_count(met2_plan *p, int64_t *count)
+{
+    if (!p || !count) return fail(MET2_E_INVALID, "NULL argument");
+    *count = p->last_spill;
     return MET2_OK;
 }
 

@@ -77,6 +77,8 @@ struct WaveShared {
                         // keep the passive set and the ranking is pure overhead (FA walk of configs[4] on 131 072 voxels: 45.0 -> 42.1 ms)
     bool buffer_rows;   // row loads of the global matrices as raw buffer loads (fit kernels); false: plain global loads (the FA walk, whose
                         // 19 MB of dictionaries at 48 x 120 missed L2 1.7x more often through the buffer path: 57 -> 66 ms per 131 k voxels)
+    double *Rg = nullptr; // this wave's spill-over slot in global memory: columns c >= kmax of the factor, entry (r, c) at col_base(c) - gbase + r
+    int gbase = 0;        // col_base(kmax)   (nnls_big.hpp; used by the BIG = true instances of the routines below only)
 };
 
 // L as 5 diagonals per owned bin: lb[b][d] = L[j][j+d-2].  (K = L^T L is not held in registers: its rows come from the
@@ -116,6 +118,7 @@ __host__ __device__ __forceinline__ constexpr int col_base(int c) { return (c * 
 
 // four / two consecutive doubles from LDS as single 8-byte reads
 typedef double met2_d2 __attribute__((ext_vector_type(2)));
+typedef double met2_d4 __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) double *met2_lds_cvp;
 __device__ __forceinline__ void lds_quad(const double *p, double &a, double &b, double &c, double &d)
 {
@@ -556,6 +559,10 @@ __device__ __forceinline__ void dual(const WaveShared &S, const Band<NB> &bd, co
     for (int b = 0; b < NB; ++b) w[b] = (lane + 64 * b < S.n) ? fma(-lam, kx[b], st.h[b] - acc[b]) : 0.0;
 }
 
+} // namespace met2
+#include "nnls_big.hpp"
+namespace met2 {
+
 // Lawson-Hanson's secondary loop: from a feasible x and a factor consistent with (P, lambda), move to
 // the solution of the passive sub-problem, dropping variables that hit zero on the way.
 // Returns false when the iteration cap is reached.
@@ -629,16 +636,19 @@ __device__ __forceinline__ bool nnls_inner(const WaveShared &S, NnlsState<NB> &s
 }
 
 // The passive-set iteration on NB position slots (the general form).
-template <int NB, bool BS1 = false>
+// BIG (here and below): the instance compiled into the spill-over voxel routine (nnls_big.hpp) -- a set that wants to outgrow the LDS capacity
+// S.kmax goes on with its columns beyond it in the wave's global slot; BIG = false flags the voxel instead (st.itmax_hit bit 1).
+template <int NB, bool BS1 = false, bool BIG = false>
 __device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
                                                    bool warm)
 {
     const int n = S.n, itmax = 3 * n;
-    int iter = 0;
+    int iter = 0, outer = 0;
+    if constexpr (BIG) if (st.k > S.kmax) { iterate_big<NB>(S, bd, st, lam, mrows, lane, warm, iter, outer); return; }      // (a warm start beyond the LDS capacity)
     MET2_CYC_BEGIN(c_in0);
     if (warm && st.k > 0 && !nnls_inner<NB, NB, BS1>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
     MET2_CYC_END(2, c_in0);
-    for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
+    for (; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows) break;
         double w[NB];
         MET2_CYC_BEGIN(c_du);
@@ -647,11 +657,15 @@ __device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Ba
         MET2_CYC_END(3, c_du);
         MET2_CYC_ADD(13, 1);
         if (st.k >= S.kmax) {
-            // capacity of the fast path reached: if a variable still wants to enter, the voxel is redone with kmax = n
+            // capacity of the wave's LDS region reached: if a variable still wants to enter, the voxel is flagged -- and solved again at once by
+            // the spill-over voxel routine, whose instance of this code (BIG) goes on here with the columns beyond the capacity in global memory
             double vmax = -1.0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) vmax = fmax(vmax, ((lane + 64 * b < n) && !((st.P[b] >> lane) & 1ull)) ? w[b] : -1.0);
-            if (wave_max(vmax) > 0.0) st.itmax_hit |= 2;
+            if (wave_max(vmax) > 0.0) {
+                if (BIG && S.Rg) { bool wf = false; iterate_big<NB>(S, bd, st, lam, mrows, lane, wf, iter, outer); }
+                else st.itmax_hit |= 2;
+            }
             break;
         }
         // entering variable: largest positive dual among Z; rejected candidates are skipped
@@ -694,7 +708,7 @@ __device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Ba
 
 // One leg of the passive-set iteration with NP position slots.  NP < NB (one slot: k <= 64) hands over to the general leg when the
 // set is about to outgrow 64 positions: returns false then ("not finished"), with iter / outer / warm carried in the arguments.
-template <int NB, int NP>
+template <int NB, int NP, bool BIG = false>
 __device__ __forceinline__ bool iterate_leg(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
                                             bool &warm, int &iter, int &outer)
 {
@@ -716,11 +730,14 @@ __device__ __forceinline__ bool iterate_leg(const WaveShared &S, const Band<NB> 
         MET2_CYC_END(3, c_du);
         MET2_CYC_ADD(13, 1);
         if (st.k >= S.kmax) {
-            // capacity of the fast path reached: if a variable still wants to enter, the voxel is redone with kmax = n
+            // capacity of the wave's LDS region reached: if a variable still wants to enter, the voxel is flagged (BIG: the spill-over leg takes over)
             double vmax = -1.0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) vmax = fmax(vmax, ((lane + 64 * b < n) && !((st.P[b] >> lane) & 1ull)) ? w[b] : -1.0);
-            if (wave_max(vmax) > 0.0) st.itmax_hit |= 2;
+            if (wave_max(vmax) > 0.0) {
+                if (BIG && S.Rg) return false;
+                st.itmax_hit |= 2;
+            }
             break;
         }
         // entering variable: largest positive dual among Z; rejected candidates are skipped
@@ -771,16 +788,20 @@ __device__ __forceinline__ bool iterate_leg(const WaveShared &S, const Band<NB> 
 // Passive-set iterations until the KKT conditions hold.  mrows = rows of the (augmented) system.
 // warm: x is a feasible point whose support is the current passive set and R/y were just rebuilt for
 // (P, lam) -- start with the secondary loop instead of from the empty set.
-template <int NB, int ONE = 0>
+template <int NB, int ONE = 0, bool BIG = false>
 __device__ __forceinline__ void nnls_iterate(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int mrows, int lane,
                                              bool warm = false)
 {
     if constexpr (NB == 2 && ONE == 1 && MET2_ONE_SLOT) {
         int iter = 0, outer = 0;
-        if (st.k <= 63 && iterate_leg<NB, 1>(S, bd, st, lam, mrows, lane, warm, iter, outer)) return;
-        (void)iterate_leg<NB, NB>(S, bd, st, lam, mrows, lane, warm, iter, outer);
+        if (st.k <= 63 && iterate_leg<NB, 1, BIG>(S, bd, st, lam, mrows, lane, warm, iter, outer)) return;
+        if constexpr (BIG) {
+            if (st.k <= S.kmax && iterate_leg<NB, NB, true>(S, bd, st, lam, mrows, lane, warm, iter, outer)) return;
+            if (S.Rg) iterate_big<NB>(S, bd, st, lam, mrows, lane, warm, iter, outer);      // the set wants to outgrow (or a warm start is beyond) the LDS capacity
+        } else
+            (void)iterate_leg<NB, NB>(S, bd, st, lam, mrows, lane, warm, iter, outer);
     } else
-        nnls_iterate_plain<NB, (NB == 2 && ONE == 3)>(S, bd, st, lam, mrows, lane, warm);
+        nnls_iterate_plain<NB, (NB == 2 && ONE == 3), BIG>(S, bd, st, lam, mrows, lane, warm);
 }
 
 template <int NB>
@@ -972,8 +993,6 @@ __device__ __forceinline__ bool refactor_rowwise(const WaveShared &S, const Band
     }
     return true;
 }
-
-typedef double met2_d4 __attribute__((ext_vector_type(4)));
 
 // Rebuild R, 1/diag and y = R^-T h_P for the CURRENT passive set and pivot order at a new lambda: blocked right-looking
 // Cholesky of A = G_PP (G = B + lam K, rows and columns in pivot order) in the packed LDS triangle.
@@ -1199,9 +1218,10 @@ __device__ __forceinline__ bool refactor_blocked(const WaveShared &S, const Band
 #ifndef MET2_REFACTOR_BLOCKED_FROM
 #define MET2_REFACTOR_BLOCKED_FROM 2        // bins per lane from which the blocked form is used
 #endif
-template <int NB, int ONE = 0>
+template <int NB, int ONE = 0, bool BIG = false>
 __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, int lane)
 {
+    if constexpr (BIG) if (st.k > S.kmax) return refactor_big<NB>(S, bd, st, lam, lane);   // beyond the LDS capacity: columns >= kmax in the wave's global slot
     if (NB == 2 && ONE && MET2_ONE_SLOT && MET2_ONE_SLOT_REFACTOR && st.k <= 64) return refactor_rowwise<NB, 1>(S, bd, st, lam, lane);   // k <= 64: one position slot, row by row
     if (NB >= MET2_REFACTOR_BLOCKED_FROM) return refactor_blocked<NB>(S, bd, st, lam, lane);
     if (MET2_DOUBLE == 1) { (void)refactor_rowwise<NB>(S, bd, st, lam, lane); __builtin_amdgcn_wave_barrier(); }
@@ -1209,11 +1229,11 @@ __device__ __forceinline__ bool refactor(const WaveShared &S, const Band<NB> &bd
 }
 
 // cold-start solve; on return st.x is the solution
-template <int NB, int ONE = 0>
+template <int NB, int ONE = 0, bool BIG = false>
 __device__ __forceinline__ void nnls_solve(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
     nnls_reset<NB>(st);
-    nnls_iterate<NB, ONE>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
+    nnls_iterate<NB, ONE, BIG>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane);
 }
 
 // Pivot order for a warm start: the passive bins by DESCENDING x.  The re-factorisation builds the factor in whatever order it is
@@ -1277,14 +1297,14 @@ __device__ __forceinline__ void reorder_by_x(const WaveShared &S, NnlsState<NB> 
 // rebuild the factor for the new lambda in the same pivot order, then iterate.  The minimiser of the
 // strictly convex problem does not depend on the starting point, so this returns the same x as the
 // cold start up to rounding; it only skips the passes that would rebuild the same passive set.
-template <int NB, int ONE = 0>
+template <int NB, int ONE = 0, bool BIG = false>
 __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<NB> &bd, NnlsState<NB> &st, double lam, bool aug, int lane)
 {
     const int kold = st.k;
-    if (kold == 0) { nnls_solve<NB, ONE>(S, bd, st, lam, aug, lane); return; }
+    if (kold == 0) { nnls_solve<NB, ONE, BIG>(S, bd, st, lam, aug, lane); return; }
     MET2_CYC_BEGIN(c_ref);
     if (NB >= MET2_REORDER && S.reorder && kold >= 4 && S.rcap >= kold + 4 + 32 * NB + 2) reorder_by_x<NB>(S, st, lane);
-    if (!refactor<NB, ONE>(S, bd, st, lam, lane)) {
+    if (!refactor<NB, ONE, BIG>(S, bd, st, lam, lane)) {
         MET2_CYC_ADD(4, 1000000000000ull);               // fallbacks show up in the 1e12 digits of the append slot
         int ordold[NB];
 #pragma unroll
@@ -1292,7 +1312,10 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
         st.k = 0;
         for (int p = 0; p < kold; ++p) {
             const int t = bcastN_i<NB>(ordold, p);
-            if (!try_append<NB>(S, bd, st, lam, t, lane, true)) {     // column became dependent: drop it
+            bool okp;
+            if constexpr (BIG) okp = (st.k >= S.kmax) ? try_append_big<NB>(S, bd, st, lam, t, lane, true) : try_append<NB>(S, bd, st, lam, t, lane, true);
+            else okp = try_append<NB>(S, bd, st, lam, t, lane, true);
+            if (!okp) {     // column became dependent: drop it
 #pragma unroll
                 for (int b = 0; b < NB; ++b) if (lane + 64 * b == t) st.x[b] = 0.0;
             }
@@ -1300,7 +1323,7 @@ __device__ __forceinline__ void nnls_solve_warm(const WaveShared &S, const Band<
     }
     MET2_CYC_END(1, c_ref);
     MET2_CYC_ADD(12, 1);
-    nnls_iterate<NB, ONE>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
+    nnls_iterate<NB, ONE, BIG>(S, bd, st, lam, aug ? S.m + S.n : S.m, lane, true);
 }
 
 // D x  (lane e < m holds (D x)_e), using the passive set of st
@@ -1354,11 +1377,13 @@ __device__ __forceinline__ void project(const WaveShared &S, double bvec, int la
 // correction computed from D brings it to the level of a QR solve of the augmented system (~cond(D_P) eps), which is what the
 // reference's Lawson-Hanson works at.  Called only where a Brent comparison sits inside the Gram-form noise (fminbound_tie_dev): a plain,
 // unpipelined forward substitution is good enough.
-template <int NB>
+template <int NB, bool BIG = false>
 __device__ __forceinline__ void refine_csne(const WaveShared &S, NnlsState<NB> &st, double lam, double bvec, int lane)
 {
     const int k = st.k;
     if (k == 0) return;
+    bool big = false;
+    if constexpr (BIG) big = k > S.kmax;                               // columns beyond the LDS capacity live in the wave's global slot (nnls_big.hpp)
     double r = bvec - model_signal<NB>(S, st, lane);
     r = (lane < S.m) ? r : 0.0;
     double g[NB];
@@ -1376,6 +1401,19 @@ __device__ __forceinline__ void refine_csne(const WaveShared &S, NnlsState<NB> &
     double u[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) { const double t = gatherN<NB>(g, st.ord[b]); u[b] = (lane + 64 * b < k) ? t : 0.0; }      // by position
+    if (BIG && big) {
+        const double *cpl[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) cpl[b] = big_col(S, min(lane + 64 * b, S.n - 1));
+        for (int i = 0; i + 1 < k; ++i) {
+            double t[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) t[b] = u[b] * st.rinv[b];
+            const double si = bcastN<NB>(t, i);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int pl = lane + 64 * b; if (pl > i && pl < k) u[b] = fma(-cpl[b][i], si, u[b]); }
+        }
+    } else
     for (int i = 0; i + 1 < k; ++i) {                                  // R^T u = g_P: row i of R is entry i of every later column
         double t[NB];
 #pragma unroll
@@ -1387,7 +1425,8 @@ __device__ __forceinline__ void refine_csne(const WaveShared &S, NnlsState<NB> &
     double ysave[NB], dl[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) { ysave[b] = st.y[b]; st.y[b] = (lane + 64 * b < k) ? u[b] * st.rinv[b] : 0.0; }
-    back_subst<NB>(S, st, lane, dl);                                   // R delta = u
+    if (BIG && big) back_subst_big<NB>(S, st, lane, dl);
+    else back_subst<NB>(S, st, lane, dl);                              // R delta = u
 #pragma unroll
     for (int b = 0; b < NB; ++b) st.y[b] = ysave[b];
 #pragma unroll
@@ -1395,6 +1434,65 @@ __device__ __forceinline__ void refine_csne(const WaveShared &S, NnlsState<NB> &
         const double d = gatherN<NB>(dl, max(st.pos[b], 0));           // by bin
         if (st.pos[b] >= 0) st.x[b] += d;
     }
+}
+
+// ---- the NOT-inlined instances of the solver with the spill-over legs compiled in (BIG = true), called by the spill-over voxel routine
+// (fit_kernel.hpp: fit_voxel_spill).  Arguments of a device function arrive in vector registers: what is wave-uniform is made scalar again
+// on entry; the factor's LDS region comes as an LDS-typed pointer beside the struct.
+__device__ __forceinline__ void big_uniform(WaveShared &S)
+{
+    S.B = big_rfl(S.B); S.K = big_rfl(S.K); S.Dt = big_rfl(S.Dt); S.DtG = big_rfl(S.DtG); S.kband = big_rfl(S.kband); S.D = big_rfl(S.D);
+    S.Rg = big_rfl(S.Rg);
+    S.dtstride = big_rfl(S.dtstride); S.n = big_rfl(S.n); S.m = big_rfl(S.m); S.bstride = big_rfl(S.bstride); S.dstride = big_rfl(S.dstride);
+    S.kmax = big_rfl(S.kmax); S.rcap = big_rfl(S.rcap); S.gbase = big_rfl(S.gbase);
+    S.have_bdiag = big_rfl((int)S.have_bdiag) != 0; S.reorder = big_rfl((int)S.reorder) != 0; S.buffer_rows = big_rfl((int)S.buffer_rows) != 0;
+}
+template <int NB>
+__device__ __forceinline__ void big_uniform(NnlsState<NB> &st)
+{
+    st.k = big_rfl(st.k); st.itmax_hit = big_rfl(st.itmax_hit);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) st.P[b] = big_rfl(st.P[b]);
+}
+// flags: bit 0 = the augmented system's row count (aug), bit 1 = warm start
+template <int NB, int ONE>
+__device__ __attribute__((noinline)) void big_solve_fn(WaveShared S, big_lds_dp Rl, Band<NB> bd, NnlsState<NB> *stp, double lam, int flags)
+{
+    const int lane = big_lane();
+    big_uniform(S);
+    S.R = (double *)Rl;
+    NnlsState<NB> st = *stp;
+    big_uniform<NB>(st);
+    lam = __hiloint2double(big_rfl(__double2hiint(lam)), big_rfl(__double2loint(lam)));
+    flags = big_rfl(flags);
+#ifdef MET2_BIGSTATS
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int k0 = st.k;
+    st.itmax_hit &= ~4;
+#endif
+    if (flags & 2) nnls_solve_warm<NB, ONE, true>(S, bd, st, lam, (flags & 1) != 0, lane);
+    else nnls_solve<NB, ONE, true>(S, bd, st, lam, (flags & 1) != 0, lane);
+#ifdef MET2_BIGSTATS
+    {
+        const unsigned long long dt = __builtin_readcyclecounter() - t0;
+        const bool big = (st.itmax_hit & 4) || k0 > S.kmax;
+        MET2_BIGSTAT(0, 1);
+        if (big) { MET2_BIGSTAT(1, 1); MET2_BIGSTAT(3, dt); MET2_BIGSTAT(7, st.k); MET2_BIGSTAT(8, k0); } else MET2_BIGSTAT(2, dt);
+    }
+#endif
+    *stp = st;
+}
+template <int NB>
+__device__ __attribute__((noinline)) void big_refine_fn(WaveShared S, big_lds_dp Rl, NnlsState<NB> *stp, double lam, double bvec)
+{
+    const int lane = big_lane();
+    big_uniform(S);
+    S.R = (double *)Rl;
+    NnlsState<NB> st = *stp;
+    big_uniform<NB>(st);
+    lam = __hiloint2double(big_rfl(__double2hiint(lam)), big_rfl(__double2loint(lam)));
+    refine_csne<NB, true>(S, st, lam, bvec, lane);
+    *stp = st;
 }
 
 // h = D^T b for the bins a lane owns (bvec: lane e holds echo e)

@@ -314,6 +314,12 @@ class Met2Plan:
         check(lib().met2_plan_last_second_pass_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_spill_count(self):
+        """Voxels of the most recent fit whose passive set outgrew the wave's LDS region and went on in the spill-over slot."""
+        n = C.c_int64(0)
+        check(lib().met2_plan_last_spill_count(self._h, C.byref(n)))
+        return n.value
+
     def gcv_form(self):
         """(low_rank, residual): whether GCV's trace is taken from the 17 x 17 form in the dictionary's low-rank basis on this plan."""
         lr, res = C.c_int32(0), C.c_double(0.0)
