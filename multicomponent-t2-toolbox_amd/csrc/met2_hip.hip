@@ -349,8 +349,9 @@ struct FaArgs {
     double *fa_index, *km, *resid;
     int *queue;
     int64_t nvox;
-    double *Hq;               // [nvox of this pass][nfa * 16]: Q_fa^T b in every flip angle's low-rank basis (fa_project_kernel on the stacked bases), or NULL: no pruning.
-                              // The walk overwrites entry [fa * 16] with the angle's lower bound (a voxel's row belongs to the one wave that walks it).
+    const double *Hq;         // [nvox of this pass][nfa * 16]: c_fa = Q_fa^T b in every flip angle's low-rank basis (fa_project_kernel on the stacked bases), or NULL: no pruning.
+    double *Lb;               // [nvox of this pass][nfa]: the walk parks every angle's lower bound here (a voxel's row belongs to the one wave that walks it)
+    const double *Aq;         // [nfa][n][16]: (Q_fa^T D_fa)^T -- with Hq, the walk forms h_fa = A_fa^T c_fa = D_fa^T (Q Q^T b) from it (round 5: no H then)
     const double *H;          // [nvox of this pass][nfa * n]: h = D_fa^T b of every flip angle (fa_project_kernel), or NULL: formed in the walk
     int64_t v0;               // first voxel of this pass (H row 0), voxels [v0, v0 + nvox_pass)
     int64_t v_end;            // one past the last voxel of this pass
@@ -481,11 +482,11 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
         auto candidates = [&](int vv) {
             const double tb = fma(best_r[vv], 1.0 + 1e-6, slack[vv]);     // sqrt(lb) > best (1 + 1e-6) + 1e-7 ||b||, compared as squares
             const double thr = tb * tb;
-            const double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
+            const double *q = A.Lb + (size_t)(v0 + vv - A.v0) * (size_t)A.nfa;
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 const int f = lane + 64 * sl;
-                const double lb = q[(size_t)min(f, A.nfa - 1) * MET2_GCV_LR_RANK];
+                const double lb = q[min(f, A.nfa - 1)];
                 cand[vv][sl] = ballot(f < A.nfa && !(lb > thr));
             }
         };
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
             slack[vv] = 0.0; fa0[vv] = -1; cand[vv][0] = cand[vv][1] = ~0ull;
             if (PRUNE && A.Hq && act[vv]) {
                 const double bb2 = wave_sum(b[vv] * b[vv]);
-                double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
+                const double *q = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK);
+                double *qb = A.Lb + (size_t)(v0 + vv - A.v0) * (size_t)A.nfa;
                 double l2[2];
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
                     if (f < A.nfa)
                         for (int j = 0; j < MET2_GCV_LR_RANK; ++j) { const double c = q[(size_t)f * MET2_GCV_LR_RANK + j]; cs = fma(c, c, cs); }
                     l2[sl] = (f < A.nfa) ? bb2 - cs : INFINITY;
-                    if (f < A.nfa) q[(size_t)f * MET2_GCV_LR_RANK] = l2[sl];
+                    if (f < A.nfa) qb[f] = l2[sl];
                 }
                 // What the bound may be off by: the basis leaves E = (I - Q Q^T) D, ||E|| <= 1e-9 of the largest column, outside, and the residual
                 // of ANY x is at least ||b_perp|| - ||E x||; with ||x||_1 <= a few ||b|| per unit column norm (x >= 0 and a dictionary of decaying
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
 #ifdef MET2_CYCSTATS
             const unsigned long long cv0 = __builtin_readcyclecounter();
 #endif
-            if (!A.H) {                        // few flip angles: no batched contraction; rows of D come from L2, each loaded once for all the wave's voxels
+            if (!A.H && !(PRUNE && A.Hq)) {    // few flip angles: no batched contraction; rows of D come from L2, each loaded once for all the wave's voxels
                 const double *Bf = A.Bfa + (size_t)i * n * n;
                 S.B = Bf; S.D = A.Dfa + (size_t)i * m * n; S.Dt = A.Dtfa + (size_t)i * m * n;
 #pragma unroll
@@ -536,14 +538,35 @@ __global__ __launch_bounds__(64 * WAVES) void fa_kernel(FaArgs A)
                 const int fa = (PRUNE && i < 0) ? fa0[vv] : i;
                 if (!act[vv] || (PRUNE && (fa < 0 || (i >= 0 && fa == fa0[vv])))) continue;
                 if (PRUNE && !((cand[vv][fa >> 6] >> (fa & 63)) & 1ull)) continue;   // its lower bound exceeds the best residual: cannot be the argmin
-                if (A.H) {                     // h of this flip angle from the batched MFMA contraction: one contiguous row per voxel
+                if (A.H || (PRUNE && A.Hq)) {
                     const double *Bf = A.Bfa + (size_t)fa * n * n;
                     S.B = Bf; S.D = A.Dfa + (size_t)fa * m * n; S.Dt = A.Dtfa + (size_t)fa * m * n;
 #pragma unroll
                     for (int bb = 0; bb < NB; ++bb) { const int j = min(lane + 64 * bb, n - 1); S.bdiag[bb] = Bf[(size_t)j * n + j]; }
-                    const double *hrow = A.H + (size_t)(v0 + vv - A.v0) * Mh + (size_t)fa * n;
+                    if (PRUNE && A.Hq) {
+                        // h = A_fa^T c_fa from the plan's low-rank basis: D_fa = Q_fa A_fa to 1e-10 of its largest column, so this is D_fa^T (Q Q^T b), and the
+                        // NNLS against the projected data has the minimiser of the NNLS against b (b - Q Q^T b is orthogonal to everything D_fa x can
+                        // reach): residuals equal to 1e-14 relative (numpy, both shapes).  16 FMAs per bin from a 128-byte row of a 1.4 MB table that
+                        // stays in L2, where the batched contraction wrote 87 KB of H per voxel at 91 x 120 and the walk read a third of it back.
+                        const double *cq = A.Hq + (size_t)(v0 + vv - A.v0) * ((size_t)A.nfa * MET2_GCV_LR_RANK) + (size_t)fa * MET2_GCV_LR_RANK;
+                        const double cl = cq[lane & (MET2_GCV_LR_RANK - 1)];
+                        const met2_d2 *aq = (const met2_d2 *)(A.Aq + (size_t)fa * n * MET2_GCV_LR_RANK);
 #pragma unroll
-                    for (int bb = 0; bb < NB; ++bb) { const int j = lane + 64 * bb; const double hv = hrow[min(j, n - 1)]; st[vv].h[bb] = (j < n) ? hv : 0.0; }
+                        for (int bb = 0; bb < NB; ++bb) {
+                            const int j = min(lane + 64 * bb, n - 1);
+                            met2_d2 av[MET2_GCV_LR_RANK / 2];
+#pragma unroll
+                            for (int t = 0; t < MET2_GCV_LR_RANK / 2; ++t) av[t] = aq[(size_t)j * (MET2_GCV_LR_RANK / 2) + t];
+                            double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+                            for (int t = 0; t < MET2_GCV_LR_RANK / 2; ++t) { h0 = fma(av[t].x, bcast(cl, 2 * t), h0); h1 = fma(av[t].y, bcast(cl, 2 * t + 1), h1); }
+                            st[vv].h[bb] = (lane + 64 * bb < n) ? h0 + h1 : 0.0;
+                        }
+                    } else {                   // h of this flip angle from the batched MFMA contraction: one contiguous row per voxel
+                        const double *hrow = A.H + (size_t)(v0 + vv - A.v0) * Mh + (size_t)fa * n;
+#pragma unroll
+                        for (int bb = 0; bb < NB; ++bb) { const int j = lane + 64 * bb; const double hv = hrow[min(j, n - 1)]; st[vv].h[bb] = (j < n) ? hv : 0.0; }
+                    }
                 }
                 nnls_solve_warm<NB, (NB == 2 && VPW == 1)>(S, bd, st[vv], 0.0, false, lane);   // one position slot (k <= nTE); with two voxels per wave the second code path stops the voxel loop from unrolling
                 const double rn = sqrt(sse_of<NB>(S, st[vv], b[vv], lane));
@@ -2047,8 +2070,10 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
     // flip angle's low-rank basis.  Pruning needs the basis to span the dictionary (p->gcv_lr), all residuals NOT to be asked for, and the
     // bounds of all angles to fit two per lane; MET2_FA_NOPRUNE=1: test switch.
     const bool prune = p->gcv_lr && !resid && p->n_fa >= 8 && p->n_fa <= 128 && !getenv("MET2_FA_NOPRUNE");      // (<= 128: the bounds are formed two per lane)
-    const int64_t Mh0 = (int64_t)p->n_fa * p->n_t2;
-    const int64_t Mh = Mh0 + (prune ? (int64_t)p->n_fa * MET2_GCV_LR_RANK : 0);
+    // round 5: a pruning walk forms its h from the low-rank basis (fa_kernel), so its scratch is the 16 coefficients per angle and the bounds --
+    // 12.4 KB per voxel at 91 angles where H took 87 KB more; the exhaustive walk (all residuals asked for; a dictionary the basis does not span) keeps H
+    const int64_t Mh0 = prune ? 0 : (int64_t)p->n_fa * p->n_t2;
+    const int64_t Mh = Mh0 + (prune ? (int64_t)p->n_fa * (MET2_GCV_LR_RANK + 1) : 0);
     const bool gemm = p->n_fa >= 8 && tuning_env("MET2_FA_GEMM", 0, 1, 1) != 0;
     int64_t pass = nvox;
     if (gemm) {
@@ -2085,7 +2110,7 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
         }                                                                                                               \
     } while (0)
     for (int64_t v0 = 0; v0 < nvox; v0 += pass) {
-        A.v0 = v0; A.v_end = std::min<int64_t>(nvox, v0 + pass); A.H = nullptr; A.Hq = nullptr;
+        A.v0 = v0; A.v_end = std::min<int64_t>(nvox, v0 + pass); A.H = nullptr; A.Hq = nullptr; A.Lb = nullptr; A.Aq = p->dAq;
         HIPCHK(hipMemsetAsync(sb.queue, 0, sizeof(int), s));
         if (gemm) {
             FaGemmArgs G;
@@ -2094,18 +2119,14 @@ int met2_fa_bruteforce_strided(met2_plan *p, int64_t nvox, const double *data, i
             const int64_t waves = (A.v_end - v0 + 31) / 32;
             const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
             const int ks = (p->n_te + 3) / 4;
+            if (prune) {                                                            // the contraction on the stacked bases: [T x m] . [m x nfa 16]
+                G.n = MET2_GCV_LR_RANK; G.Dtfa = p->dQt;
+                A.Hq = p->dH; A.Lb = p->dH + (size_t)pass * p->n_fa * MET2_GCV_LR_RANK;
+            } else A.H = p->dH;
             if (ks <= 8)       hipLaunchKernelGGL(fa_project_kernel<8>, grid, block, 0, s, G);
             else if (ks <= 12) hipLaunchKernelGGL(fa_project_kernel<12>, grid, block, 0, s, G);
             else               hipLaunchKernelGGL(fa_project_kernel<16>, grid, block, 0, s, G);
-            if (prune) {                                                            // the same contraction on the stacked bases: [T x m] . [m x nfa 16]
-                G.n = MET2_GCV_LR_RANK; G.Dtfa = p->dQt; G.H = p->dH + (size_t)pass * Mh0;
-                if (ks <= 8)       hipLaunchKernelGGL(fa_project_kernel<8>, grid, block, 0, s, G);
-                else if (ks <= 12) hipLaunchKernelGGL(fa_project_kernel<12>, grid, block, 0, s, G);
-                else               hipLaunchKernelGGL(fa_project_kernel<16>, grid, block, 0, s, G);
-                A.Hq = G.H;
-            }
             HIPCHK(hipGetLastError());
-            A.H = p->dH;
         }
         if (g.nb == 1) { if (g.waves == 16) MET2_FA_LAUNCH(2, 1, 16); else MET2_FA_LAUNCH(4, 1, 8); }
         else           { if (g.waves == 16) MET2_FA_LAUNCH(1, 2, 16); else MET2_FA_LAUNCH(2, 2, 8); }   // two voxels per wave at two bins per lane: same 57 ms (measured)
