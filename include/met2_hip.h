@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MET2_ABI_VERSION 5
+#define MET2_ABI_VERSION 6
 
 /* reg_method of motor/motor_recon_met2_real_data.py:134-150 */
 enum met2_method {
@@ -84,6 +84,12 @@ typedef struct met2_options {
     int32_t reserved0;
     double t2_myelin_cut;     /* motor:216 (myelin_T2 CLI flag)   40.0                     */
     double t2_ie_cut;         /* motor:217            200.0                                */
+    /* ABI 6: the intervals of the lambda searches (scipy.optimize.fminbound's x1, x2).  A caller that passes a shorter struct (struct_size of
+     * ABI <= 5) gets the reference values.  0 <= lo < hi, finite.  The plan-level seeds and BayesReg's factor tables follow them.  */
+    double x2_lo, x2_hi;      /* algorithms.py:219              0, 10     (the reference's evaluation scripts search wider grids: :215 of
+                                                                          evaluate_all_methods_two_lobes_SNR50_150.py tops at 100)          */
+    double gcv_lo, gcv_hi;    /* algorithms.py:280              1e-8, 10  */
+    double bayes_lo, bayes_hi;/* bayesian_interpolation.py:101  1e-8, 2   */
 } met2_options;
 
 void met2_default_options(met2_options *opt);

@@ -17,7 +17,8 @@ class Met2Error(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("x2_factor", C.c_double), ("t2sparc_lambda", C.c_double),
                 ("brent_xtol", C.c_double), ("brent_maxfun", C.c_int32), ("reserved0", C.c_int32), ("t2_myelin_cut", C.c_double),
-                ("t2_ie_cut", C.c_double)]
+                ("t2_ie_cut", C.c_double), ("x2_lo", C.c_double), ("x2_hi", C.c_double), ("gcv_lo", C.c_double), ("gcv_hi", C.c_double),
+                ("bayes_lo", C.c_double), ("bayes_hi", C.c_double)]
 
 
 # every symbol include/met2_hip.h declares

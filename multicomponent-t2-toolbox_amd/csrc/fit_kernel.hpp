@@ -43,6 +43,7 @@ struct FitArgs {
     int method, nlam, maxfun;
     double x2_factor, t2sparc_lambda, xtol;
     double cut_m, cut_ie;
+    double lam_lo, lam_hi;                // the interval of the method's lambda search (met2_options: x2_lo .. bayes_hi)
     double log_detL;
     const double *Dfa;    // [nfa][m][n]
     const double *Bfa;    // [nfa][n][n]
@@ -412,8 +413,8 @@ __host__ __device__ constexpr int method_max_waves(int method, int nb = 1)
 struct SeedArgs {
     int n, m, nfa;
     const double *Dfa, *Bfa, *Dtfa, *kband, *lband, *Kd;
-    double lam[3];          // slot 0: X2 and GCV (bounds 0 / 1e-8 .. 10), slot 1: BayesReg (1e-8 .. 2), slot 2: T2SPARC's fixed lambda
-    char *out;              // [3][nfa] SeedRec
+    double lam[4];          // slot 0: X2, slot 1: BayesReg, slot 2: T2SPARC's fixed lambda, slot 3: GCV (the first Brent abscissa of each method's interval)
+    char *out;              // [4][nfa] SeedRec
 };
 // one record per (slot, flip angle): a single kernel-argument pointer reaches all of it (the fit kernels are short of SGPRs)
 struct SeedRec {
@@ -590,7 +591,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             best_sse = last_sse;
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
-        }, 0.0, 10.0, A.xtol, A.maxfun, flag, nref);
+        }, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag, nref);
         if (MET2_TIE_GUARD == 2 && nref) stat |= 64 | (nref & 0x1f00);
 #else
         double lam = fminbound_dev([&](double x) {
@@ -624,7 +625,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             best_sse = last_sse;
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
-        }, 0.0, 10.0, A.xtol, A.maxfun, flag);
+        }, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag);
 #endif
         if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
         if (lam != last_x && !(NB == 2 && (st.itmax_hit & 2))) {
@@ -712,7 +713,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             }
             ++ev;
             return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab, cholG);
-        }, []() {}, 1e-8, 2.0, A.xtol, A.maxfun, flag);
+        }, []() {}, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag);
         if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
         if (bc.failed) stat |= MET2_ST_CHOLFAIL;
         if (!(NB == 2 && (st.itmax_hit & 2))) solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
@@ -726,7 +727,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
             solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
             return gcv_objective<NB, METHOD == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
-        }, []() {}, 1e-8, 10.0, A.xtol, A.maxfun, flag);
+        }, []() {}, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag);
         if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
         if (overflow) stat |= MET2_ST_KOVERFLOW;
         if (!(NB == 2 && (st.itmax_hit & 2))) solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);

@@ -1017,8 +1017,8 @@ struct met2_plan {
     // sort buffers (grown on demand)
     int64_t cap_vox = 0;
     int *dKey = nullptr, *dPerm = nullptr, *dSmall = nullptr, *dOvf = nullptr;
-    char *dSeed = nullptr;                                // seed_kernel's output: [3][nfa] SeedRec
-    bool seeds_valid = false; double seeds_t2sparc = 0.0; // (the T2SPARC slot was solved at this lambda)
+    char *dSeed = nullptr;                                // seed_kernel's output: [4][nfa] SeedRec
+    bool seeds_valid = false; double seeds_key[7] = {0};  // (t2sparc_lambda and the six interval ends the seeds and tables were built for)
     bool seeds_ok = false;                                // B + lambda K is positive definite at the seed lambdas (checked on the host for
                                                           // flip angle 0): only then is the seeded start the cold start's solution
     double *dH = nullptr; int64_t cap_h = 0;              // FA walk: h of every flip angle for one pass of voxels (fa_project_kernel), grown on demand
@@ -1427,13 +1427,16 @@ static bool host_posdef(int n, std::vector<double> G)
 static int ensure_seeds(met2_plan *p, hipStream_t s)
 {
     if (!p->have_dict || !p->have_pen) return MET2_OK;
-    if (p->seeds_valid && p->seeds_t2sparc == p->opt.t2sparc_lambda) return MET2_OK;
+    const double key[7] = {p->opt.t2sparc_lambda, p->opt.x2_lo, p->opt.x2_hi, p->opt.gcv_lo, p->opt.gcv_hi, p->opt.bayes_lo, p->opt.bayes_hi};
+    if (p->seeds_valid && memcmp(key, p->seeds_key, sizeof(key)) == 0) return MET2_OK;
     const int n = p->n_t2;
     const double gm = 0.5 * (3.0 - sqrt(5.0));
     SeedArgs SA;
     SA.n = n; SA.m = p->n_te; SA.nfa = p->n_fa;
     SA.Dfa = p->dD; SA.Bfa = p->dB; SA.Dtfa = p->dDt; SA.kband = p->dKband; SA.lband = p->dLband; SA.Kd = p->dKd;
-    SA.lam[0] = gm * 10.0; SA.lam[1] = 1e-8 + gm * (2.0 - 1e-8); SA.lam[2] = p->opt.t2sparc_lambda;
+    // the first abscissa of scipy's bounded Brent on each method's interval, a + g (b - a); T2SPARC's fixed lambda
+    SA.lam[0] = p->opt.x2_lo + gm * (p->opt.x2_hi - p->opt.x2_lo); SA.lam[1] = p->opt.bayes_lo + gm * (p->opt.bayes_hi - p->opt.bayes_lo);
+    SA.lam[2] = p->opt.t2sparc_lambda; SA.lam[3] = p->opt.gcv_lo + gm * (p->opt.gcv_hi - p->opt.gcv_lo);
     SA.out = p->dSeed;
     {
         std::vector<double> B0((size_t)n * n), K((size_t)n * n);
@@ -1441,7 +1444,7 @@ static int ensure_seeds(met2_plan *p, hipStream_t s)
         HIPCHK(hipMemcpy(B0.data(), p->dB, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(K.data(), p->dKd, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
         bool ok = true;
-        for (int q = 0; q < 3 && ok; ++q) {
+        for (int q = 0; q < 4 && ok; ++q) {
             std::vector<double> G((size_t)n * n);
             for (size_t i = 0; i < G.size(); ++i) G[i] = B0[i] + SA.lam[q] * K[i];
             ok = SA.lam[q] > 0.0 && host_posdef(n, G);
@@ -1451,16 +1454,16 @@ static int ensure_seeds(met2_plan *p, hipStream_t s)
     const int lds = (int)sizeof(double) * col_base(n) + 64;
     if (n <= 64) {
         HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
+        hipLaunchKernelGGL(seed_kernel<1>, dim3(p->n_fa, 4), dim3(64), lds, s, SA);
     } else {
         HIPCHK(hipFuncSetAttribute((const void *)seed_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 3), dim3(64), lds, s, SA);
+        hipLaunchKernelGGL(seed_kernel<2>, dim3(p->n_fa, 4), dim3(64), lds, s, SA);
     }
     HIPCHK(hipGetLastError());
     if (MET2_BAYES_TABLE > 0) {
-        // BayesReg's shared abscissae on [1e-8, 2] (fminbound_dev with an objective that decreases towards the lower bound):
-        // a + g (b - a), one golden step up, then golden steps down
-        const double a = 1e-8, b = 2.0;
+        // BayesReg's shared abscissae on its interval ([1e-8, 2] in the reference; fminbound_dev with an objective that decreases towards
+        // the lower bound): a + g (b - a), one golden step up, then golden steps down
+        const double a = p->opt.bayes_lo, b = p->opt.bayes_hi;
         BayesTabArgs TA;
         TA.n = n; TA.m = p->n_te; TA.nfa = p->n_fa; TA.nj = MET2_BAYES_TABLE;
         TA.Bfa = p->dB; TA.Kd = p->dKd; TA.kband = p->dKband; TA.lband = p->dLband;
@@ -1485,7 +1488,7 @@ static int ensure_seeds(met2_plan *p, hipStream_t s)
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(s));
-    p->seeds_valid = true; p->seeds_t2sparc = p->opt.t2sparc_lambda;
+    p->seeds_valid = true; memcpy(p->seeds_key, key, sizeof(key));
     return MET2_OK;
 }
 
@@ -1502,6 +1505,21 @@ void met2_default_options(met2_options *o)
     o->brent_maxfun = 0;
     o->t2_myelin_cut = 40.0;
     o->t2_ie_cut = 200.0;
+    o->x2_lo = 0.0; o->x2_hi = 10.0;             // algorithms.py:219
+    o->gcv_lo = 1e-8; o->gcv_hi = 10.0;          // algorithms.py:280
+    o->bayes_lo = 1e-8; o->bayes_hi = 2.0;       // bayesian_interpolation.py:101
+}
+
+// a caller's options struct may be shorter than ours (an earlier ABI): what it does not carry keeps the value already in `dst`
+static int take_options(met2_options *dst, const met2_options *src)
+{
+    if (src->struct_size < (int32_t)(2 * sizeof(int32_t))) return fail(MET2_E_INVALID, "met2_options.struct_size not set");
+    memcpy(dst, src, sizeof(met2_options) < (size_t)src->struct_size ? sizeof(met2_options) : (size_t)src->struct_size);
+    dst->struct_size = (int32_t)sizeof(met2_options);
+    const double iv[3][2] = {{dst->x2_lo, dst->x2_hi}, {dst->gcv_lo, dst->gcv_hi}, {dst->bayes_lo, dst->bayes_hi}};
+    for (int q = 0; q < 3; ++q)
+        if (!(iv[q][0] >= 0.0) || !(iv[q][1] > iv[q][0]) || !std::isfinite(iv[q][1])) return fail(MET2_E_INVALID, "lambda-search interval: 0 <= lo < hi (finite) required");
+    return MET2_OK;
 }
 
 int met2_abi_version(void) { return MET2_ABI_VERSION; }
@@ -1525,8 +1543,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MET2_E_NODEVICE, "no HIP device visible");
     met2_plan *p = new met2_plan();
     p->n_te = n_te; p->n_t2 = n_t2; p->n_fa = n_fa;
-    if (opt) { memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size); }
-    else met2_default_options(&p->opt);
+    met2_default_options(&p->opt);
+    if (opt) { const int rco = take_options(&p->opt, opt); if (rco) { delete p; return rco; } }
     if (p->opt.device < 0 || p->opt.device >= ndev) { delete p; return fail(MET2_E_INVALID, "device ordinal out of range"); }
     DevGuard dev_guard_(p->opt.device);
     if (dev_guard_.err != hipSuccess) { delete p; return fail(MET2_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(dev_guard_.err)); }
@@ -1545,7 +1563,7 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMemset(p->dKd, 0, sizeof(double) * (size_t)n_t2 * n_t2));
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
-    HIPCHK(hipMalloc(&p->dSeed, sizeof(SeedRec) * 3 * (size_t)n_fa));
+    HIPCHK(hipMalloc(&p->dSeed, sizeof(SeedRec) * 4 * (size_t)n_fa));
     HIPCHK(hipHostMalloc((void **)&p->hErr, 2 * sizeof(int), hipHostMallocDefault));
     p->hErr[0] = p->hErr[1] = 0;
     HIPCHK(hipEventCreate(&p->ev0));
@@ -1561,7 +1579,13 @@ int met2_plan_set_options(met2_plan *p, const met2_options *opt)
 {
     if (!p || !opt) return fail(MET2_E_INVALID, "NULL argument");
     if (opt->device != p->opt.device) return fail(MET2_E_INVALID, "a plan cannot change device");
-    memcpy(&p->opt, opt, sizeof(met2_options) < (size_t)opt->struct_size ? sizeof(met2_options) : (size_t)opt->struct_size);
+    {
+        met2_options o = p->opt;
+        const int rco = take_options(&o, opt);
+        if (rco) return rco;
+        if (o.device != p->opt.device) return fail(MET2_E_INVALID, "a plan stays on the device it was created on");
+        p->opt = o;
+    }
     USE_DEVICE(p->opt.device);
     return ensure_seeds(p, 0);       // T2SPARC's seed belongs to its lambda
 }
@@ -1897,15 +1921,17 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     A.maxfun = p->opt.brent_maxfun > 0 ? p->opt.brent_maxfun : (method == MET2_BAYESREG ? 200 : 300);
     A.x2_factor = p->opt.x2_factor; A.t2sparc_lambda = p->opt.t2sparc_lambda; A.xtol = p->opt.brent_xtol;
     A.cut_m = p->opt.t2_myelin_cut; A.cut_ie = p->opt.t2_ie_cut;
+    A.lam_lo = method == MET2_GCV ? p->opt.gcv_lo : (method == MET2_BAYESREG ? p->opt.bayes_lo : p->opt.x2_lo);       // the lambda search's interval
+    A.lam_hi = method == MET2_GCV ? p->opt.gcv_hi : (method == MET2_BAYESREG ? p->opt.bayes_hi : p->opt.x2_hi);
     A.log_detL = p->log_detL;
     A.Dfa = p->dD; A.Bfa = p->dB; A.Dtfa = p->dDt; A.Aq = p->dAq; A.kband = p->dKband; A.lband = p->dLband; A.Kd = p->dKd; A.lam_grid = p->dLam; A.t2s = p->dT2;
     A.data = data; A.vs = voxel_stride; A.es = echo_stride; A.sb = sb; A.fsol = fsol; A.sig = sig; A.reg = reg; A.lam = lam; A.maps = maps; A.status = status; A.nvox = nvox;
 
     A.seed = nullptr;
     const bool no_seed = getenv("MET2_NO_SEED") != nullptr;      // test switch: every voxel grows its first passive set from the lambda = 0 solution
-    if (!no_seed && !objgrid && p->have_pen && p->seeds_valid && p->seeds_ok && p->seeds_t2sparc == p->opt.t2sparc_lambda &&
+    if (!no_seed && !objgrid && p->have_pen && p->seeds_valid && p->seeds_ok && p->seeds_key[0] == p->opt.t2sparc_lambda &&
         (method == MET2_X2 || method == MET2_GCV || method == MET2_BAYESREG || method == MET2_T2SPARC)) {
-        const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : 0);      // records built by ensure_seeds() when the plan was configured
+        const int slot = method == MET2_BAYESREG ? 1 : (method == MET2_T2SPARC ? 2 : (method == MET2_GCV ? 3 : 0));      // records built by ensure_seeds() when the plan was configured
         A.seed = p->dSeed + sizeof(SeedRec) * (size_t)slot * p->n_fa;
     }
     A.btab = nullptr; A.nbtab = 0; A.btab_stride = p->btab_stride;

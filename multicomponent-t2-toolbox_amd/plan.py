@@ -101,7 +101,8 @@ class Met2Plan:
 
     # ---- configuration
     def set_options(self, **kw):
-        """x2_factor, t2sparc_lambda, brent_xtol, brent_maxfun, t2_myelin_cut, t2_ie_cut"""
+        """x2_factor, t2sparc_lambda, brent_xtol, brent_maxfun, t2_myelin_cut, t2_ie_cut, and the lambda-search intervals x2_lo / x2_hi,
+        gcv_lo / gcv_hi, bayes_lo / bayes_hi (scipy's fminbound bounds at algorithms.py:219, :280, bayesian_interpolation.py:101)"""
         opt = Options()
         check(lib().met2_plan_get_options(self._h, C.byref(opt)))
         for k, v in kw.items():
@@ -114,7 +115,8 @@ class Met2Plan:
     def get_options(self, *names):
         opt = Options()
         check(lib().met2_plan_get_options(self._h, C.byref(opt)))
-        return {k: getattr(opt, k) for k in (names or ("x2_factor", "t2sparc_lambda", "brent_xtol", "brent_maxfun", "t2_myelin_cut", "t2_ie_cut"))}
+        return {k: getattr(opt, k) for k in (names or ("x2_factor", "t2sparc_lambda", "brent_xtol", "brent_maxfun", "t2_myelin_cut", "t2_ie_cut",
+                                                           "x2_lo", "x2_hi", "gcv_lo", "gcv_hi", "bayes_lo", "bayes_hi"))}
 
     def build_dictionary_epg(self, T2s, T1s, tau, alpha_values, TR):
         (_, p2), (_, p1), (_, pa) = _h(T2s), _h(T1s), _h(alpha_values)

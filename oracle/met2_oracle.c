@@ -490,13 +490,21 @@ static double obj_x2(double x, void *v)
     double SSEr = o_sse(c->D, c->f, c->M, c->m, c->n);
     return fabs(SSEr - c->factor * c->SSE) / c->SSE;
 }
+/* The intervals of the three lambda searches: the reference's literals (algorithms.py:219, :280, bayesian_interpolation.py:101) unless a test
+ * sets others (met2o_set_intervals: the product takes them from met2_options since ABI 6).  Process-wide; set before a batch, not during one. */
+static double g_iv[6] = {0.0, 10.0, 1e-8, 10.0, 1e-8, 2.0};
+MET2O_API void met2o_set_intervals(const double *iv6)
+{
+    static const double dflt[6] = {0.0, 10.0, 1e-8, 10.0, 1e-8, 2.0};
+    for (int i = 0; i < 6; ++i) g_iv[i] = iv6 ? iv6[i] : dflt[i];
+}
 static void o_x2(vox_ctx *c, double factor, double *f, double *lam, double *kest, int *st, brent_trace *tr)
 {
     double rn; int flag;
     solve_plain(c, c->f, &rn);
     c->SSE = o_sse(c->D, c->f, c->M, c->m, c->n);
     c->factor = factor;
-    *lam = o_fminbound(obj_x2, c, 0.0, 10.0, 1e-5, 300, NULL, &flag, tr);
+    *lam = o_fminbound(obj_x2, c, g_iv[0], g_iv[1], 1e-5, 300, NULL, &flag, tr);
     if (flag == 1) *st |= ST_BRENT_MAXFUN;
     solve_aug(c, *lam, f, &rn);
     *kest = o_sse(c->D, f, c->M, c->m, c->n) / c->SSE;
@@ -626,7 +634,7 @@ static double obj_gcv(double x, void *v)
 static void o_gcv(vox_ctx *c, double *f, double *lam, int *st, brent_trace *tr)
 {
     double rn; int flag;
-    *lam = o_fminbound(obj_gcv, c, 1e-8, 10.0, 1e-5, 300, NULL, &flag, tr);
+    *lam = o_fminbound(obj_gcv, c, g_iv[2], g_iv[3], 1e-5, 300, NULL, &flag, tr);
     if (flag == 1) *st |= ST_BRENT_MAXFUN;
     solve_aug(c, *lam, f, &rn);
 }
@@ -704,7 +712,7 @@ static void o_bayes(vox_ctx *c, double *f, double *lam, int *st, brent_trace *tr
 {
     double rn; int flag;
     bayes_prepare(c);
-    *lam = o_fminbound(obj_bayes, c, 1e-8, 2.0, 1e-5, 200, NULL, &flag, tr);
+    *lam = o_fminbound(obj_bayes, c, g_iv[4], g_iv[5], 1e-5, 200, NULL, &flag, tr);
     if (flag == 1) *st |= ST_BRENT_MAXFUN;
     solve_aug(c, *lam, f, &rn);
 }

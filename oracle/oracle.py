@@ -152,7 +152,15 @@ def fminbound_poly(c, r, p, x1, x2, xatol=1e-5, maxfun=300, cap=400):
 
 # ------------------------------------------------------------------ batches
 def fit_batch(method, D_fa_major, L, data, fa_index, mask, lambda_reg=None, x2_factor=1.02, t2sparc_lambda=1.8, nthreads=1,
-              want_lambda=False):
+              want_lambda=False, intervals=None):
+    """intervals: (x2_lo, x2_hi, gcv_lo, gcv_hi, bayes_lo, bayes_hi) of the lambda searches; None = the reference's literals."""
+    if intervals is not None:
+        iv = _d(np.asarray(intervals, dtype=np.float64).reshape(6))
+        lib().met2o_set_intervals(_p(iv))
+        try:
+            return fit_batch(method, D_fa_major, L, data, fa_index, mask, lambda_reg, x2_factor, t2sparc_lambda, nthreads, want_lambda)
+        finally:
+            lib().met2o_set_intervals(None)
     D = _d(D_fa_major)
     nfa, nte, nt2 = D.shape
     data = _d(data); nvox = data.shape[0]

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_header_symbols():
     for name in declared:
         assert hasattr(L, name), "libmet2_hip.so does not export %s" % name
     assert set(lib.SYMBOLS) == declared
-    assert L.met2_abi_version() == 5
+    assert L.met2_abi_version() == 6
 
 
 def test_no_cpu_fallback_without_gpu():
