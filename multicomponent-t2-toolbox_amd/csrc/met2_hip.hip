@@ -1080,6 +1080,14 @@ static int ensure_sort_bufs(met2_plan *p, int64_t nvox)
     return MET2_OK;
 }
 
+// met2_fit_host reserves a plan's per-voxel scratch for its largest block before the block loop (met2_host.hip)
+namespace met2 { __attribute__((visibility("hidden"))) int plan_reserve(met2_plan *p, int64_t nvox)
+{
+    if (!p) return fail(MET2_E_INVALID, "NULL plan");
+    USE_DEVICE(p->opt.device);
+    return ensure_sort_bufs(p, nvox);
+} }
+
 static SortBufs sort_bufs(met2_plan *p)
 {
     SortBufs sb;

@@ -27,7 +27,10 @@
 #include "../../include/met2_hip.h"
 #include "abi_common.hpp"
 
-namespace met2 { __attribute__((visibility("hidden"))) void spline_tables_release(); }
+namespace met2 {
+__attribute__((visibility("hidden"))) void spline_tables_release();
+__attribute__((visibility("hidden"))) int plan_reserve(met2_plan *plan, int64_t nvox);      // the plan's per-voxel scratch for blocks of nvox voxels (met2_hip.hip)
+}
 
 namespace {
 
@@ -155,12 +158,18 @@ void host_copy(void *dst, const void *src, size_t bytes)
     const int parts = 4;
     const size_t step = ((bytes / parts) + 63) & ~(size_t)63;
     std::thread helpers[parts - 1];
+    int started = 0;
     for (int i = 1; i < parts; ++i) {
         const size_t lo = std::min(bytes, step * i), hi = std::min(bytes, step * (i + 1));
-        helpers[i - 1] = std::thread([=] { if (hi > lo) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+        try { helpers[i - 1] = std::thread([=] { if (hi > lo) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); }); ++started; }
+        catch (...) { break; }                  // no thread to be had (a pids limit, say): the calling thread copies the rest itself
     }
     memcpy(dst, src, std::min(bytes, step));
-    for (auto &h : helpers) h.join();
+    for (int i = started + 1; i < parts; ++i) {
+        const size_t lo = std::min(bytes, step * i), hi = std::min(bytes, step * (i + 1));
+        if (hi > lo) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo);
+    }
+    for (int i = 0; i < started; ++i) helpers[i].join();
 }
 
 // `rows` rows of row_bytes each, pitches in bytes: the rows are dealt to the calling thread and up to three helpers when there is enough to copy
@@ -170,9 +179,14 @@ void host_copy_rows(char *dst, size_t dst_pitch, const char *src, size_t src_pit
     if (row_bytes * (size_t)rows < ((size_t)8 << 20) || rows < 4) { run(0, rows); return; }
     const int parts = 4;
     std::thread helpers[parts - 1];
-    for (int i = 1; i < parts; ++i) helpers[i - 1] = std::thread(run, rows * i / parts, rows * (i + 1) / parts);
+    int started = 0;
+    for (int i = 1; i < parts; ++i) {
+        try { helpers[i - 1] = std::thread(run, rows * i / parts, rows * (i + 1) / parts); ++started; }
+        catch (...) { break; }                  // (as in host_copy)
+    }
     run(0, rows / parts);
-    for (auto &h : helpers) h.join();
+    for (int i = started + 1; i < parts; ++i) run(rows * i / parts, rows * (i + 1) / parts);
+    for (int i = 0; i < started; ++i) helpers[i].join();
 }
 
 struct Job {
@@ -180,7 +194,7 @@ struct Job {
     const double *data; const double *fa_data; int64_t vs, es;
     const double *fa_index; const uint8_t *mask; const double *mask_values; int estimate_fa;
     double *fsol, *sig, *reg, *lam, *maps; int32_t *status; double *fa_out, *fa_gate;
-    int64_t chunk; int nte, nt2; bool split;
+    int64_t chunk; int64_t run; int nte, nt2; bool split;     // run: voxels per dealt run (0: one plan, contiguous blocks)
     // which host arrays the device reaches directly
     bool pin_data, pin_fa_data, pin_fa, pin_mask, pin_mv, pin_gate, pin_fsol, pin_sig, pin_reg, pin_lam, pin_maps, pin_status, pin_fa_out;
     Regions stage;            // the arrays that go through the pinned slab
@@ -216,22 +230,35 @@ int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, const 
     const int need_lr = J.estimate_fa == 2 ? (int)at.alpha_lr.size() : 0;
     const bool need_fa_in = J.fa_data != nullptr;
     const bool grow = w->cap < J.chunk || w->nte != J.nte || w->nt2 != J.nt2 || w->nlr < need_lr || (need_fa_in && !w->fa_in);
-    if (grow) {
+    // a failed allocation leaves the Work EMPTY (cap = 0, no slabs), never half-sized: the shape is committed only once every slab exists, so the
+    // next call -- on this plan, or on the plan that takes this Work from the pool -- allocates again instead of running on a NULL slab
+    auto drop_all = [&]() {
         for (Slot &s : w->slot) {
-            if (s.dev) { HIPCHK(hipFree(s.dev)); s.dev = nullptr; }
-            if (s.pin) { HIPCHK(hipHostFree(s.pin)); s.pin = nullptr; }
+            if (s.dev) { (void)hipFree(s.dev); s.dev = nullptr; }
+            if (s.pin) { (void)hipHostFree(s.pin); s.pin = nullptr; }
         }
-        w->pin_bytes = 0;
-        w->cap = std::max(w->cap, J.chunk); w->nte = J.nte; w->nt2 = J.nt2; w->nlr = std::max(w->nlr, need_lr); w->fa_in = w->fa_in || need_fa_in;
-        Regions all; all.in_fa = w->fa_in; all.nlr = w->nlr;
-        const Layout L(w->cap, w->nte, w->nt2, all);
-        for (Slot &s : w->slot) HIPCHK(hipMalloc((void **)&s.dev, L.total));
+        w->cap = 0; w->pin_bytes = 0;
+    };
+    if (grow) {
+        const int64_t cap = std::max(w->cap, J.chunk);
+        const int nlr = std::max(w->nlr, need_lr);
+        const bool fa_in = w->fa_in || need_fa_in;
+        drop_all();
+        Regions all; all.in_fa = fa_in; all.nlr = nlr;
+        const Layout L(cap, J.nte, J.nt2, all);
+        for (Slot &s : w->slot) {
+            const hipError_t e = hipMalloc((void **)&s.dev, L.total);
+            if (e != hipSuccess) { (void)hipGetLastError(); s.dev = nullptr; drop_all(); return fail(MET2_E_HIP, std::string("hipMalloc of a block slot: ") + hipGetErrorString(e)); }
+        }
+        w->cap = cap; w->nte = J.nte; w->nt2 = J.nt2; w->nlr = nlr; w->fa_in = fa_in;
     }
     const size_t pin_need = need_pin ? Layout(w->cap, w->nte, w->nt2, J.stage).total : 0;
     if (pin_need > w->pin_bytes) {
+        for (Slot &s : w->slot) if (s.pin) { (void)hipHostFree(s.pin); s.pin = nullptr; }
+        w->pin_bytes = 0;
         for (Slot &s : w->slot) {
-            if (s.pin) { HIPCHK(hipHostFree(s.pin)); s.pin = nullptr; }
-            HIPCHK(hipHostMalloc((void **)&s.pin, pin_need, hipHostMallocDefault));
+            const hipError_t e = hipHostMalloc((void **)&s.pin, pin_need, hipHostMallocDefault);
+            if (e != hipSuccess) { (void)hipGetLastError(); s.pin = nullptr; drop_all(); return fail(MET2_E_HIP, std::string("hipHostMalloc of a staging slab: ") + hipGetErrorString(e)); }
         }
         w->pin_bytes = pin_need;
     }
@@ -239,113 +266,163 @@ int ensure_work(met2_plan *plan, int device, const Job &J, bool need_pin, const 
     return MET2_OK;
 }
 
-// one plan's share of the job: blocks t, t + n_plans, t + 2 n_plans, ...
+// One plan's share of the job.
+// Dealing (J.run): with several plans the voxel list is dealt in RUNS of 4 096 voxels, run j -> plan j mod n_plans (the granularity of dist.py's
+// interleave: background, CSF and white matter cluster along the slow axis and differ 10x in iteration count), and a plan's DMA block is `chunk`
+// voxels of ITS runs -- chunk / 4 096 runs that lie n_plans runs apart in the caller's arrays, moved by one pitched (2-D) copy per array and
+// direction.  With one plan (J.run == 0) a block is a contiguous range, as before.  Until round 5 whole blocks of 65 536 - 262 144 voxels were
+// dealt round-robin: 16 - 64 times coarser than the distributed driver.
 int pipeline(const Job &J, int t, Work *w, const Attach &at)
 {
     met2_plan *plan = J.plans[t];
     const int nte = J.nte, nt2 = J.nt2;
-    const int64_t chunk = J.chunk;
-    const int64_t nblocks = (J.nvox + chunk - 1) / chunk;
-    // this plan's pieces of the voxel list: its blocks, with the first one split 1/8 + 7/8 and the last one 7/8 + 1/8 -- the upload of the
-    // very first piece and the download of the very last one are the only copies that do not run under a fit, so they are made short
-    // (configs[1], one plan, four blocks of 262 144: 166.7 -> see DESIGN section 7; a piece costs ~1.9 ms of queue tail and sort passes)
-    std::vector<std::pair<int64_t, int64_t>> seg;           // (first voxel, voxels)
-    for (int64_t b = t; b < nblocks; b += J.n_plans) seg.emplace_back(b * chunk, std::min<int64_t>(chunk, J.nvox - b * chunk));
+    const int64_t chunk = J.chunk, run = J.run;
+    const int NP = J.n_plans;
+    // a segment: n voxels of this plan starting at voxel g0 of the caller's list -- contiguous (run == 0), or runs at g0, g0 + NP run, ...
+    struct Seg { int64_t g0, n; };
+    std::vector<Seg> seg;
+    if (run == 0) {
+        const int64_t nblocks = (J.nvox + chunk - 1) / chunk;
+        for (int64_t b = t; b < nblocks; b += NP) seg.push_back({b * chunk, std::min<int64_t>(chunk, J.nvox - b * chunk)});
+    } else {
+        const int64_t nruns = (J.nvox + run - 1) / run, cr = chunk / run;            // (chunk is a multiple of run)
+        const int64_t mine_runs = t < nruns ? (nruns - t + NP - 1) / NP : 0;
+        for (int64_t r0 = 0; r0 < mine_runs; r0 += cr) {
+            const int64_t r1 = std::min(mine_runs, r0 + cr), jl = t + (r1 - 1) * NP;  // jl: the block's last run in the caller's list
+            seg.push_back({(t + r0 * NP) * run, (r1 - 1 - r0) * run + std::min<int64_t>(run, J.nvox - jl * run)});
+        }
+    }
+    auto advance = [&](int64_t g0, int64_t e) { return run ? g0 + (e / run) * NP * run : g0 + e; };   // the voxel e places further on in this plan's share (e: whole runs)
+    // the first block is split 1/8 + 7/8 and the last one 7/8 + 1/8 -- the upload of the very first piece and the download of the very last one
+    // are the only copies that do not run under a fit, so they are made short (a piece costs ~1.5 ms of queue tail and spill-over kernel)
     if (J.split && !seg.empty()) {
         auto eighth = [](int64_t n) { return n >= 131072 ? std::max<int64_t>(4096, (n / 8) & ~(int64_t)4095) : 0; };      // (smaller blocks are not worth two more pieces)
-        {   const auto last = seg.back(); const int64_t e = eighth(last.second);
-            if (e) { seg.back() = {last.first, last.second - e}; seg.emplace_back(last.first + last.second - e, e); } }
-        {   const auto first = seg.front(); const int64_t e = eighth(first.second);
-            if (e) { seg.front() = {first.first + e, first.second - e}; seg.insert(seg.begin(), {first.first, e}); } }
+        {   const Seg last = seg.back(); const int64_t e = eighth(last.n), keep = run ? ((last.n - e + run - 1) / run) * run : last.n - e;
+            if (e && keep > 0 && keep < last.n) { seg.back() = {last.g0, keep}; seg.push_back({advance(last.g0, keep), last.n - keep}); } }
+        {   const Seg first = seg.front(); const int64_t e = eighth(first.n);
+            if (e && e < first.n) { seg.front() = {advance(first.g0, e), first.n - e}; seg.insert(seg.begin(), {first.g0, e}); } }
     }
     const int64_t mine = (int64_t)seg.size();
     Regions all_; all_.in_fa = w->fa_in; all_.nlr = w->nlr;
     const Layout L(w->cap, nte, nt2, all_);          // device slab
     const Layout P(w->cap, nte, nt2, J.stage);       // pinned slab
-    auto lo_of = [&](int64_t c) { return seg[(size_t)c].first; };
-    auto n_of = [&](int64_t c) { return seg[(size_t)c].second; };
     const bool stage_in = !J.pin_data || J.in_case == 2;
     // the block on the device: voxel-major [n][nte] (cases 0 and 2) or echo-major [nte][n] (case 1); read in place either way
     const bool dev_echo_major = J.in_case == 1;
 
-    // one input block (the volume, or the volume the FA step sees): host -> the slot's region at `off`, in the layout the kernels read
-    auto put_block = [&](Slot &S, size_t off, size_t poff, const double *src, bool stage, int64_t lo, int64_t n) -> int {
-        double *d_in = (double *)(S.dev + off);
-        if (stage) {
-            double *h = (double *)(S.pin + poff);
-            if (J.in_case == 0) {
-                if (J.vs == nte) host_copy(h, src + lo * J.vs, sizeof(double) * (size_t)n * nte);
-                else host_copy_rows((char *)h, sizeof(double) * nte, (const char *)(src + lo * J.vs), sizeof(double) * (size_t)J.vs, sizeof(double) * nte, n);
-            } else if (J.in_case == 1) {
-                host_copy_rows((char *)h, sizeof(double) * (size_t)n, (const char *)(src + lo), sizeof(double) * (size_t)J.es, sizeof(double) * (size_t)n, nte);
-            } else {
-                for (int64_t v = 0; v < n; ++v)
-                    for (int e = 0; e < nte; ++e) h[v * nte + e] = src[(lo + v) * J.vs + e * J.es];
-            }
-            HIPCHK(hipMemcpyAsync(d_in, h, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
-        } else if (J.in_case == 0) {
-            // (hipMemcpyDefault: the source is pinned host memory or, for a volume that a filter left on a device, device memory)
-            if (J.vs == nte) HIPCHK(hipMemcpyAsync(d_in, src + lo * J.vs, sizeof(double) * (size_t)n * nte, hipMemcpyDefault, w->s_in));
-            else HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * nte, src + lo * J.vs, sizeof(double) * J.vs, sizeof(double) * nte, (size_t)n,
-                                         hipMemcpyDefault, w->s_in));
-        } else {
-            HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * (size_t)n, src + lo, sizeof(double) * J.es, sizeof(double) * (size_t)n, (size_t)nte,
-                                    hipMemcpyDefault, w->s_in));
+    // ---- a per-voxel array of the caller (rb bytes per voxel, voxel 0 at `host`) against the block's packed copy
+    // the contiguous pieces of a segment: fn(first voxel in the caller's list, offset inside the block, voxels)
+    auto pieces = [&](const Seg &sg, auto &&fn) {
+        if (run == 0) { fn(sg.g0, (int64_t)0, sg.n); return; }
+        for (int64_t off = 0, g = sg.g0; off < sg.n; off += run, g += (int64_t)NP * run) fn(g, off, std::min<int64_t>(run, sg.n - off));
+    };
+    // block <-> host array on the calling thread (and helpers when the block is large): staging of pageable arrays
+    auto host_side = [&](char *packed, char *host, size_t rb, const Seg &sg, bool to_packed) {
+        if (run == 0 || sg.n <= run) {
+            if (to_packed) host_copy(packed, host + (size_t)sg.g0 * rb, (size_t)sg.n * rb); else host_copy(host + (size_t)sg.g0 * rb, packed, (size_t)sg.n * rb);
+            return;
         }
+        const int64_t nf = sg.n / run, tail = sg.n % run;
+        if (to_packed) host_copy_rows(packed, (size_t)run * rb, host + (size_t)sg.g0 * rb, (size_t)NP * run * rb, (size_t)run * rb, nf);
+        else host_copy_rows(host + (size_t)sg.g0 * rb, (size_t)NP * run * rb, packed, (size_t)run * rb, (size_t)run * rb, nf);
+        if (tail) {
+            char *hp = host + (size_t)(sg.g0 + nf * NP * run) * rb, *pp = packed + (size_t)nf * run * rb;
+            if (to_packed) memcpy(pp, hp, (size_t)tail * rb); else memcpy(hp, pp, (size_t)tail * rb);
+        }
+    };
+    // block <-> host array by the device's copy engines (pinned or device-resident host side): one pitched copy for the whole runs, one for a tail
+    auto dma = [&](char *dev, char *host, size_t rb, const Seg &sg, bool to_dev, hipStream_t st) -> int {
+        const hipMemcpyKind kind = to_dev ? hipMemcpyDefault : hipMemcpyDeviceToHost;      // (hipMemcpyDefault: a volume that a filter left on a device is a device pointer)
+        if (run == 0 || sg.n <= run) {
+            char *hp = host + (size_t)sg.g0 * rb;
+            HIPCHK(hipMemcpyAsync(to_dev ? (void *)dev : (void *)hp, to_dev ? (const void *)hp : (const void *)dev, (size_t)sg.n * rb, kind, st));
+            return MET2_OK;
+        }
+        const int64_t nf = sg.n / run, tail = sg.n % run;
+        char *hp = host + (size_t)sg.g0 * rb;
+        const size_t wd = (size_t)run * rb, hpitch = (size_t)NP * run * rb;
+        if (to_dev) HIPCHK(hipMemcpy2DAsync(dev, wd, hp, hpitch, wd, (size_t)nf, kind, st));
+        else HIPCHK(hipMemcpy2DAsync(hp, hpitch, dev, wd, wd, (size_t)nf, kind, st));
+        if (tail) {
+            char *ht = host + (size_t)(sg.g0 + nf * NP * run) * rb, *dt = dev + (size_t)nf * run * rb;
+            HIPCHK(hipMemcpyAsync(to_dev ? (void *)dt : (void *)ht, to_dev ? (const void *)ht : (const void *)dt, (size_t)tail * rb, kind, st));
+        }
+        return MET2_OK;
+    };
+    // host array -> device block: through the pinned slab's room `stage` when the array is pageable (stage != NULL), else straight
+    auto to_device = [&](char *dev, const void *host, size_t rb, const Seg &sg, char *stage) -> int {
+        if (!stage) return dma(dev, (char *)host, rb, sg, true, w->s_in);
+        host_side(stage, (char *)host, rb, sg, true);
+        HIPCHK(hipMemcpyAsync(dev, stage, (size_t)sg.n * rb, hipMemcpyHostToDevice, w->s_in));
+        return MET2_OK;
+    };
+    // device block -> host array, or -> the pinned slab's room for it (drain() copies on)
+    auto from_device = [&](char *dev, void *host, size_t rb, const Seg &sg, char *stage) -> int {
+        if (!host) return MET2_OK;
+        if (!stage) return dma(dev, (char *)host, rb, sg, false, w->s_out);
+        HIPCHK(hipMemcpyAsync(stage, dev, (size_t)sg.n * rb, hipMemcpyDeviceToHost, w->s_out));
+        return MET2_OK;
+    };
+
+    // one input block (the volume, or the volume the FA step sees): host -> the slot's region at `off`, in the layout the kernels read
+    auto put_block = [&](Slot &S, size_t off, size_t poff, const double *src, bool stage, const Seg &sg) -> int {
+        char *d_in = S.dev + off, *h = stage ? S.pin + poff : nullptr;
+        const int64_t n = sg.n;
+        int rc_ = MET2_OK;
+        if (J.in_case == 0 && J.vs == nte) return to_device(d_in, src, sizeof(double) * (size_t)nte, sg, h);
+        if (J.in_case == 1) {                          // echo-major: every echo is a per-voxel array of its own
+            for (int e = 0; e < nte && !rc_; ++e)
+                rc_ = to_device(d_in + sizeof(double) * (size_t)e * n, src + (size_t)e * J.es, sizeof(double), sg, h ? h + sizeof(double) * (size_t)e * n : nullptr);
+            return rc_;
+        }
+        // rows with a pitch, or general strides: contiguous blocks only (fit_host_impl deals whole blocks for these layouts)
+        const int64_t lo = sg.g0;
+        if (stage) {
+            double *hd = (double *)h;
+            if (J.in_case == 0) host_copy_rows((char *)hd, sizeof(double) * nte, (const char *)(src + lo * J.vs), sizeof(double) * (size_t)J.vs, sizeof(double) * nte, n);
+            else
+                for (int64_t v = 0; v < n; ++v)
+                    for (int e = 0; e < nte; ++e) hd[v * nte + e] = src[(lo + v) * J.vs + e * J.es];
+            HIPCHK(hipMemcpyAsync(d_in, hd, sizeof(double) * (size_t)n * nte, hipMemcpyHostToDevice, w->s_in));
+        } else
+            HIPCHK(hipMemcpy2DAsync(d_in, sizeof(double) * nte, src + lo * J.vs, sizeof(double) * J.vs, sizeof(double) * nte, (size_t)n, hipMemcpyDefault, w->s_in));
         return MET2_OK;
     };
     const bool stage_fa_in = J.fa_data && (!J.pin_fa_data || J.in_case == 2);
 
     auto upload = [&](int64_t c) -> int {
         Slot &S = w->slot[c & 1];
-        const int64_t lo = lo_of(c), n = n_of(c);
+        const Seg &sg = seg[(size_t)c];
         if (stage_in || stage_fa_in || (J.fa_index && !J.pin_fa) || (J.mask && !J.pin_mask) || (J.mask_values && !J.pin_mv))
             if (c >= 2) HIPCHK(hipEventSynchronize(S.ev_in));        // the H2D of block c - 2 has left this pinned slot
         if (c >= 2) {                                                 // the device slot is free once block c - 2 has been fitted and its
             HIPCHK(hipStreamWaitEvent(w->s_in, S.ev_fit, 0));         // outputs (the FA indices live in it) copied out: waited for on the
             HIPCHK(hipStreamWaitEvent(w->s_in, S.ev_out, 0));         // GPU, not by this thread
         }
-        int rc_ = put_block(S, L.in, P.in, J.data, stage_in, lo, n);
+        int rc_ = put_block(S, L.in, P.in, J.data, stage_in, sg);
         if (rc_) return rc_;
-        if (J.fa_data && (rc_ = put_block(S, L.in_fa, P.in_fa, J.fa_data, stage_fa_in, lo, n))) return rc_;
-        if (J.fa_index) {
-            const double *src = J.fa_index + lo;
-            if (!J.pin_fa) { memcpy(S.pin + P.fa, src, sizeof(double) * (size_t)n); src = (const double *)(S.pin + P.fa); }
-            HIPCHK(hipMemcpyAsync(S.dev + L.fa, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, w->s_in));
-        }
-        if (J.mask) {
-            const uint8_t *src = J.mask + lo;
-            if (!J.pin_mask) { memcpy(S.pin + P.mk, src, (size_t)n); src = (const uint8_t *)(S.pin + P.mk); }
-            HIPCHK(hipMemcpyAsync(S.dev + L.mk, src, (size_t)n, hipMemcpyHostToDevice, w->s_in));
-        }
-        if (J.mask_values) {
-            const double *src = J.mask_values + lo;
-            if (!J.pin_mv) { memcpy(S.pin + P.mv, src, sizeof(double) * (size_t)n); src = (const double *)(S.pin + P.mv); }
-            HIPCHK(hipMemcpyAsync(S.dev + L.mv, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, w->s_in));
-        }
+        if (J.fa_data && (rc_ = put_block(S, L.in_fa, P.in_fa, J.fa_data, stage_fa_in, sg))) return rc_;
+        if (J.fa_index && (rc_ = to_device(S.dev + L.fa, J.fa_index, sizeof(double), sg, J.pin_fa ? nullptr : S.pin + P.fa))) return rc_;
+        if (J.mask && (rc_ = to_device(S.dev + L.mk, J.mask, 1, sg, J.pin_mask ? nullptr : S.pin + P.mk))) return rc_;
+        if (J.mask_values && (rc_ = to_device(S.dev + L.mv, J.mask_values, sizeof(double), sg, J.pin_mv ? nullptr : S.pin + P.mv))) return rc_;
         HIPCHK(hipEventRecord(S.ev_in, w->s_in));
         return MET2_OK;
     };
 
-    // D2H of one output array of block c: straight into the caller's (pinned) array, or into the pinned slot for drain()
-    auto d2h = [&](Slot &S, size_t off, size_t poff, void *user, bool direct, size_t bytes) -> int {
-        if (!user) return MET2_OK;
-        HIPCHK(hipMemcpyAsync(direct ? user : (void *)(S.pin + poff), S.dev + off, bytes, hipMemcpyDeviceToHost, w->s_out));
-        return MET2_OK;
-    };
     auto drain = [&](int64_t c) -> int {
         Slot &S = w->slot[c & 1];
-        const int64_t lo = lo_of(c), n = n_of(c);
+        const Seg &sg = seg[(size_t)c];
+        const int64_t n = sg.n;
         HIPCHK(hipEventSynchronize(S.ev_out));
-        if (!J.pin_fsol) host_copy(J.fsol + lo * nt2, S.pin + P.fsol, sizeof(double) * (size_t)n * nt2);
-        if (J.sig && !J.pin_sig) host_copy(J.sig + lo * nte, S.pin + P.sig, sizeof(double) * (size_t)n * nte);
-        if (!J.pin_reg) memcpy(J.reg + lo, S.pin + P.reg, sizeof(double) * (size_t)n);
-        if (J.lam && !J.pin_lam) memcpy(J.lam + lo, S.pin + P.lam, sizeof(double) * (size_t)n);
+        if (!J.pin_fsol) host_side(S.pin + P.fsol, (char *)J.fsol, sizeof(double) * (size_t)nt2, sg, false);
+        if (J.sig && !J.pin_sig) host_side(S.pin + P.sig, (char *)J.sig, sizeof(double) * (size_t)nte, sg, false);
+        if (!J.pin_reg) host_side(S.pin + P.reg, (char *)J.reg, sizeof(double), sg, false);
+        if (J.lam && !J.pin_lam) host_side(S.pin + P.lam, (char *)J.lam, sizeof(double), sg, false);
         if (J.maps && !J.pin_maps)
-            for (int i = 0; i < 6; ++i) memcpy(J.maps + (size_t)i * J.nvox + lo, S.pin + P.maps + sizeof(double) * (size_t)i * n, sizeof(double) * (size_t)n);
-        if (J.status && !J.pin_status) memcpy(J.status + lo, S.pin + P.status, sizeof(int32_t) * (size_t)n);
-        if (J.fa_out && !J.pin_fa_out && J.estimate_fa) memcpy(J.fa_out + lo, S.pin + P.fa, sizeof(double) * (size_t)n);
-        if (J.fa_gate && !J.pin_gate) memcpy(J.fa_gate + lo, S.pin + P.gate, sizeof(double) * (size_t)n);
+            for (int i = 0; i < 6; ++i) host_side(S.pin + P.maps + sizeof(double) * (size_t)i * n, (char *)(J.maps + (size_t)i * J.nvox), sizeof(double), sg, false);
+        if (J.status && !J.pin_status) host_side(S.pin + P.status, (char *)J.status, sizeof(int32_t), sg, false);
+        if (J.fa_out && !J.pin_fa_out && J.estimate_fa) host_side(S.pin + P.fa, (char *)J.fa_out, sizeof(double), sg, false);
+        if (J.fa_gate && !J.pin_gate) host_side(S.pin + P.gate, (char *)J.fa_gate, sizeof(double), sg, false);
         return MET2_OK;
     };
 
@@ -353,7 +430,8 @@ int pipeline(const Job &J, int t, Work *w, const Attach &at)
     if (mine > 0 && (rc = upload(0))) return rc;
     for (int64_t c = 0; c < mine; ++c) {
         Slot &S = w->slot[c & 1];
-        const int64_t lo = lo_of(c), n = n_of(c);
+        const Seg &sg = seg[(size_t)c];
+        const int64_t n = sg.n;
         HIPCHK(hipStreamWaitEvent(w->s_fit, S.ev_in, 0));
         if (c >= 2) HIPCHK(hipStreamWaitEvent(w->s_fit, S.ev_out, 0));            // the outputs of block c - 2 have left this slot
         const double *d_in = (const double *)(S.dev + L.in);
@@ -392,32 +470,32 @@ int pipeline(const Job &J, int t, Work *w, const Attach &at)
         if (rc) return rc;
         HIPCHK(hipEventRecord(S.ev_fit, w->s_fit));
         HIPCHK(hipStreamWaitEvent(w->s_out, S.ev_fit, 0));
-        if ((rc = d2h(S, L.fsol, P.fsol, J.fsol + lo * nt2, J.pin_fsol, sizeof(double) * (size_t)n * nt2))) return rc;
-        if ((rc = d2h(S, L.sig, P.sig, J.sig ? J.sig + lo * nte : nullptr, J.pin_sig, sizeof(double) * (size_t)n * nte))) return rc;
-        if ((rc = d2h(S, L.reg, P.reg, J.reg + lo, J.pin_reg, sizeof(double) * (size_t)n))) return rc;
-        if ((rc = d2h(S, L.lam, P.lam, J.lam ? J.lam + lo : nullptr, J.pin_lam, sizeof(double) * (size_t)n))) return rc;
+        if ((rc = from_device(S.dev + L.fsol, J.fsol, sizeof(double) * (size_t)nt2, sg, J.pin_fsol ? nullptr : S.pin + P.fsol))) return rc;
+        if ((rc = from_device(S.dev + L.sig, J.sig, sizeof(double) * (size_t)nte, sg, J.pin_sig ? nullptr : S.pin + P.sig))) return rc;
+        if ((rc = from_device(S.dev + L.reg, J.reg, sizeof(double), sg, J.pin_reg ? nullptr : S.pin + P.reg))) return rc;
+        if ((rc = from_device(S.dev + L.lam, J.lam, sizeof(double), sg, J.pin_lam ? nullptr : S.pin + P.lam))) return rc;
         if (J.maps) {
             if (J.pin_maps) {
                 for (int i = 0; i < 6; ++i)
-                    HIPCHK(hipMemcpyAsync(J.maps + (size_t)i * J.nvox + lo, S.dev + L.maps + sizeof(double) * (size_t)i * n, sizeof(double) * (size_t)n,
-                                          hipMemcpyDeviceToHost, w->s_out));
-            } else if ((rc = d2h(S, L.maps, P.maps, J.maps, false, sizeof(double) * (size_t)n * 6))) return rc;
+                    if ((rc = from_device(S.dev + L.maps + sizeof(double) * (size_t)i * n, J.maps + (size_t)i * J.nvox, sizeof(double), sg, nullptr))) return rc;
+            } else HIPCHK(hipMemcpyAsync(S.pin + P.maps, S.dev + L.maps, sizeof(double) * (size_t)n * 6, hipMemcpyDeviceToHost, w->s_out));
         }
-        if ((rc = d2h(S, L.status, P.status, J.status ? J.status + lo : nullptr, J.pin_status, sizeof(int32_t) * (size_t)n))) return rc;
+        if ((rc = from_device(S.dev + L.status, J.status, sizeof(int32_t), sg, J.pin_status ? nullptr : S.pin + P.status))) return rc;
         // (the estimated indices only: given ones are copied host to host below -- the pinned slot's FA array is the staging area of the
         //  NEXT block's given indices by the time this block is drained)
-        if (J.fa_out && J.estimate_fa && (rc = d2h(S, L.fa, P.fa, J.fa_out + lo, J.pin_fa_out, sizeof(double) * (size_t)n))) return rc;
-        if ((rc = d2h(S, L.gate, P.gate, J.fa_gate ? J.fa_gate + lo : nullptr, J.pin_gate, sizeof(double) * (size_t)n))) return rc;
+        if (J.fa_out && J.estimate_fa && (rc = from_device(S.dev + L.fa, J.fa_out, sizeof(double), sg, J.pin_fa_out ? nullptr : S.pin + P.fa))) return rc;
+        if ((rc = from_device(S.dev + L.gate, J.fa_gate, sizeof(double), sg, J.pin_gate ? nullptr : S.pin + P.gate))) return rc;
         HIPCHK(hipEventRecord(S.ev_out, w->s_out));
         if (c + 1 < mine && (rc = upload(c + 1))) return rc;                       // staged and enqueued while the device works on block c
         if (c >= 1 && (rc = drain(c - 1))) return rc;
     }
     if (mine > 0 && (rc = drain(mine - 1))) return rc;
     if (J.fa_out && !J.estimate_fa)                                                // the given indices, or flip angle 0 for every voxel
-        for (int64_t c = 0; c < mine; ++c) {
-            if (J.fa_index) { if (J.fa_out != J.fa_index) memmove(J.fa_out + lo_of(c), J.fa_index + lo_of(c), sizeof(double) * (size_t)n_of(c)); }
-            else memset(J.fa_out + lo_of(c), 0, sizeof(double) * (size_t)n_of(c));
-        }
+        for (int64_t c = 0; c < mine; ++c)
+            pieces(seg[(size_t)c], [&](int64_t g, int64_t, int64_t cnt) {
+                if (J.fa_index) { if (J.fa_out != J.fa_index) memmove(J.fa_out + g, J.fa_index + g, sizeof(double) * (size_t)cnt); }
+                else memset(J.fa_out + g, 0, sizeof(double) * (size_t)cnt);
+            });
     rc = met2_plan_finish(plan, w->s_fit);                                         // waits for the fits; reports an FA index outside the dictionary
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(w->s_out));
@@ -426,7 +504,15 @@ int pipeline(const Job &J, int t, Work *w, const Attach &at)
 
 struct Outcome { int rc = MET2_OK; std::string msg; double ms = 0.0; };
 
+void run_plan_body(const Job &J, int t, bool need_pin, bool spawned, Outcome *out);
+// a C++ exception (std::bad_alloc, a thread that cannot be started) must not leave a plan's thread -- std::terminate would take the host process down
 void run_plan(const Job &J, int t, bool need_pin, bool spawned, Outcome *out)
+{
+    try { run_plan_body(J, t, need_pin, spawned, out); }
+    catch (const std::exception &e) { out->rc = MET2_E_HIP; out->msg = std::string("C++ exception: ") + e.what(); }
+    catch (...) { out->rc = MET2_E_HIP; out->msg = "unknown C++ exception"; }
+}
+void run_plan_body(const Job &J, int t, bool need_pin, bool spawned, Outcome *out)
 {
     const auto t0 = std::chrono::steady_clock::now();
     met2_options opt;
@@ -439,6 +525,10 @@ void run_plan(const Job &J, int t, bool need_pin, bool spawned, Outcome *out)
         if (it != g_attach.end()) at = it->second;
     }
     if (!rc) rc = ensure_work(J.plans[t], opt.device, J, need_pin, at, &w);
+    // the plan's sort scratch for the largest block, once: growing it block by block (the first piece is an eighth of a block) frees device
+    // memory twice per call, and hipFree waits for every stream of the device
+    if (!rc) rc = met2::plan_reserve(J.plans[t], J.chunk);
+    if (!rc && J.estimate_fa == 2 && at.plan_lr) rc = met2::plan_reserve(at.plan_lr, J.chunk);
     if (!rc) {
         DevGuard guard(opt.device);
         rc = pipeline(J, t, w, at);
@@ -549,10 +639,16 @@ static int fit_host_impl(met2_plan *const *plans, int32_t n_plans, int32_t metho
     if (fa_data && !estimate_fa) return fail(MET2_E_INVALID, "fa_data is what the FA estimation sees: it needs estimate_fa 1 or 2");
     if (estimate_fa == 2) {
         std::lock_guard<std::mutex> lock(g_work_mutex);
+        std::vector<met2_plan *> coarse;
         for (int t = 0; t < n_plans; ++t) {
             auto it = g_attach.find(plans[t]);
             if (it == g_attach.end() || !it->second.plan_lr)
                 return fail(MET2_E_STATE, "estimate_fa = 2 needs met2_plan_attach_fa_spline on every plan first");
+            // every plan's thread runs the FA walk on ITS coarse plan (queue word, scratch): one coarse plan per plan, none of them fitted here
+            met2_plan *lr = it->second.plan_lr;
+            for (met2_plan *q : coarse) if (q == lr) return fail(MET2_E_INVALID, "met2_fit_host: the same coarse plan attached to two plans (one plan serves one stream at a time)");
+            for (int u = 0; u < n_plans; ++u) if (plans[u] == lr) return fail(MET2_E_INVALID, "met2_fit_host: a coarse plan of the spline FA step is itself in plans[]");
+            coarse.push_back(lr);
         }
     }
     if (chunk < 0) return fail(MET2_E_INVALID, "chunk < 0");
@@ -570,11 +666,16 @@ static int fit_host_impl(met2_plan *const *plans, int32_t n_plans, int32_t metho
     }
     chunk = std::min<int64_t>(chunk, nvox);
     if (chunk > 0x7fffffff) return fail(MET2_E_INVALID, "chunk out of range");
+    // several plans: the list is dealt in runs of 4 096 voxels (pipeline()); the layouts whose blocks are moved by pitched copies already (rows
+    // with a pitch, general strides) keep whole blocks.  MET2_HOST_BLOCKS=1: whole blocks always (A/B switch).
+    const bool interleave = n_plans > 1 && (voxel_stride == 1 || (echo_stride == 1 && voxel_stride == nte)) && getenv("MET2_HOST_BLOCKS") == nullptr;
+    if (interleave) chunk = (chunk + 4095) / 4096 * 4096;
 
     Job J;
     J.plans = plans; J.n_plans = n_plans; J.method = method; J.nvox = nvox; J.data = data; J.fa_data = fa_data; J.vs = voxel_stride; J.es = echo_stride;
     J.fa_index = fa_index; J.mask = mask; J.estimate_fa = estimate_fa; J.fsol = fsol; J.sig = sig; J.reg = reg; J.lam = lam; J.maps = maps;
     J.status = status; J.fa_out = fa_out; J.fa_gate = fa_gate; J.mask_values = mask_values; J.chunk = chunk; J.nte = nte; J.nt2 = nt2;
+    J.run = interleave ? 4096 : 0;
     J.split = getenv("MET2_HOST_NOSPLIT") == nullptr;            // test / A-B switch: whole blocks only
     J.in_case = echo_stride == 1 ? 0 : (voxel_stride == 1 ? 1 : 2);
     if (J.in_case == 0 && voxel_stride < nte) return fail(MET2_E_INVALID, "met2_fit_host: voxel_stride < n_te with echo_stride 1 (overlapping voxels)");

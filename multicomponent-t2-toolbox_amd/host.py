@@ -113,8 +113,17 @@ def fit_host(plans, method, data, fa_index=None, mask=None, estimate_fa=False, c
             fa_data = np.asarray(fa_data, dtype=np.float64)
             if fa_data.shape != data.shape:
                 raise ValueError("fa_data must have the shape of data")
-            lay = np.empty_like(data)            # same memory layout as data
+            if not (data.flags.c_contiguous or data.flags.f_contiguous):
+                # a strided view (say big[:, :n_te]): np.empty_like would hand back a COMPACT array, and the one pair of strides the C entry takes
+                # would then be wrong for fa_data -- both arrays go in compact instead
+                if on_device:
+                    raise ValueError("a device fa_data must have the memory layout of data")
+                data = np.ascontiguousarray(data)
+                vs, es = nte, 1
+                order = "C"
+            lay = np.empty_like(data)            # same memory layout as data (C- or Fortran-contiguous here)
             lay[...] = fa_data
+            assert lay.strides == data.strides
             fa_data = lay
 
     def per_voxel(a, dt, what):

@@ -106,3 +106,149 @@ def test_options_struct_of_an_earlier_abi_is_accepted():
     assert got.x2_factor == 1.05 and (got.x2_lo, got.x2_hi, got.gcv_lo, got.gcv_hi, got.bayes_lo, got.bayes_hi) == (0.0, 10.0, 1e-8, 10.0, 1e-8, 2.0)
     assert got.struct_size == C.sizeof(lib.Options)
     L.met2_plan_destroy(h)
+
+
+def _plans(pkg, n, nfa=1, pen="L2", alphas=None, nte=32, nt2=60, device=0):
+    synth = importlib.import_module(PKG + ".synth")
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    al = np.array([150.0]) if alphas is None else alphas
+    out = []
+    for i in range(n):
+        p = pkg.Met2Plan(nte, nt2, len(al), device=device if np.isscalar(device) else device[i])
+        p.build_dictionary_epg(T2s, T1s, 10.0, al, 3000.0).set_penalty(pen, T2s).set_t2_grid(T2s)
+        out.append(p)
+    return out
+
+
+@gpu
+def test_host_entry_strided_view_with_a_separate_fa_volume():
+    """data = big[:, :n_te] (row pitch > n_te) together with an fa_data of another layout -- the two must reach the C entry with ONE
+    pair of strides that is right for both.  Equal to the same call on compact copies."""
+    import torch
+    pkg = importlib.import_module(PKG)
+    host = importlib.import_module(PKG + ".host")
+    nvox, nte = 3000, 32
+    _, _, _, _, d = _problem(nvox, 21)
+    rng = np.random.default_rng(2)
+    big = np.zeros((nvox, nte + 8)); big[:, :nte] = d; big[:, nte:] = rng.uniform(size=(nvox, 8)) * 1e3
+    view = big[:, :nte]
+    fa_vol = d * (1.0 + 0.01 * rng.standard_normal(d.shape))        # what the FA step sees: compact, C-ordered
+    alphas = np.linspace(120.0, 180.0, 13)
+    plan, = _plans(pkg, 1, alphas=alphas)
+    a = host.fit_host(plan, "X2", view, estimate_fa=True, fa_data=fa_vol, want_lambda=True)
+    b = host.fit_host(plan, "X2", np.ascontiguousarray(view), estimate_fa=True, fa_data=np.ascontiguousarray(fa_vol), want_lambda=True)
+    for k in ("fsol", "sig", "reg", "lam", "fa_index", "maps", "status"):
+        assert np.array_equal(a[k], b[k]), k
+    plan.close()
+
+
+@gpu
+@pytest.mark.parametrize("layout", ["C", "F"])
+def test_host_entry_deals_runs_of_4096_voxels_over_the_plans(layout):
+    """Several plans: the voxel list is dealt in runs of 4 096 voxels (run j -> plan j mod n_plans), a plan's block being chunk / 4 096 of ITS runs
+    moved by pitched copies.  Any number of plans, pinned or pageable arrays, C-ordered list or Fortran-ordered volume, a ragged tail: bit-equal
+    to one plan over the whole list (and to the whole-block dealing of round 4, MET2_HOST_BLOCKS=1)."""
+    import torch
+    pkg = importlib.import_module(PKG)
+    host = importlib.import_module(PKG + ".host")
+    nvox = 5 * 4096 * 3 + 1234                                       # 15 whole runs and a ragged one
+    _, _, _, _, d = _problem(nvox, 31)
+    rng = np.random.default_rng(3)
+    mask = rng.uniform(size=nvox) > 0.1
+    data = d if layout == "C" else np.asfortranarray(d.reshape(nvox, 1, 1, 32))      # (Fortran order: echo-major, every echo one contiguous row of voxels)
+    plans = _plans(pkg, 3, alphas=np.linspace(120.0, 180.0, 7))
+    ref = host.fit_host(plans[0], "X2", data, mask=mask, estimate_fa=True, want_lambda=True)
+    for n, chunk in ((2, 0), (3, 8192), (3, 5000)):
+        got = host.fit_host(plans[:n], "X2", data, mask=mask, estimate_fa=True, want_lambda=True, chunk=chunk)
+        for k in ("fsol", "sig", "reg", "lam", "fa_index", "maps", "status"):
+            assert np.array_equal(got[k], ref[k]), (n, chunk, k)
+    os.environ["MET2_HOST_BLOCKS"] = "1"
+    try:
+        got = host.fit_host(plans, "X2", data, mask=mask, estimate_fa=True, want_lambda=True, chunk=8192)
+    finally:
+        del os.environ["MET2_HOST_BLOCKS"]
+    for k in ("fsol", "lam", "fa_index"):
+        assert np.array_equal(got[k], ref[k]), k
+    # pinned arrays: the DMA engines reach the caller's arrays themselves (pitched copies in both directions)
+    pin = torch.from_numpy(np.ascontiguousarray(d)).pin_memory()
+    got = host.fit_host(plans, "X2", pin.numpy(), mask=mask, estimate_fa=True, want_lambda=True, chunk=8192)
+    ref_c = ref if layout == "C" else host.fit_host(plans[0], "X2", d, mask=mask, estimate_fa=True, want_lambda=True)
+    for k in ("fsol", "sig", "reg", "lam", "fa_index", "maps", "status"):
+        assert np.array_equal(got[k], ref_c[k]), ("pinned", k)
+    for p in plans:
+        p.close()
+
+
+# ---- paths that need two devices: skipped on a one-GPU box, so the driver's GPU test tier stays green there; they run on the first multi-GPU lease
+def _two_gpus():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@gpu
+def test_host_entry_over_two_devices_equals_one_fit():
+    """met2_fit_host with one plan per DEVICE (motor:427-441 is one process): devices [0, 1], runs of 4 096 voxels dealt
+    alternately, every device's copies over its own PCIe link -- bit-equal to one met2_fit on device 0."""
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    import torch
+    pkg = importlib.import_module(PKG)
+    host = importlib.import_module(PKG + ".host")
+    nvox = 9 * 4096 + 777
+    _, _, _, _, d = _problem(nvox, 41)
+    alphas = np.linspace(120.0, 180.0, 13)
+    plans = _plans(pkg, 2, alphas=alphas, device=[0, 1])
+    got = host.fit_host(plans, "X2", d, estimate_fa=True, want_lambda=True)
+    assert got["plan_ms"].shape == (2,) and (got["plan_ms"] > 0).all()
+    with torch.cuda.device(0):
+        dd = torch.as_tensor(d, device="cuda:0")
+        fa, _, _ = plans[0].fa_bruteforce(dd)
+        ref = plans[0].fit("X2", dd, fa_index=fa, want_lambda=True)
+    for k in ("fsol", "sig", "reg", "lam", "maps"):
+        assert np.array_equal(got[k], ref[k].cpu().numpy()), k
+    assert np.array_equal(got["fa_index"], fa.cpu().numpy())
+    for p in plans:
+        p.close()
+
+
+_RCCL2_WORKER = r"""
+import os, sys, importlib
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+pkg = importlib.import_module(%(pkg)r)
+d = importlib.import_module(%(pkg)r + ".dist")
+synth = importlib.import_module(%(pkg)r + ".synth")
+rank, local, world = d.init(backend="nccl")                     # one process per GPU, RCCL over xGMI
+assert world == 2 and dist.get_backend() == "nccl" and torch.cuda.current_device() == local
+nte, nt2, nvox = 32, 60, 20000
+T2s = synth.t2_grid(nt2)
+plan = pkg.Met2Plan(nte, nt2, 1, device=local)
+plan.build_dictionary_epg(T2s, 1000.0 * np.ones(nt2), 10.0, np.array([150.0]), 3000.0).set_penalty("L2", T2s)
+data, _, _ = synth.make_voxels(nvox, nte=nte, seed=11, device="cuda:%%d" %% local)
+out, full = d.fit_sharded(lambda idx: plan.fit("X2", data[idx].contiguous()), nvox, gather=("fsol", "sig", "reg", "maps"))
+torch.cuda.synchronize()
+if rank == 0:
+    ref = plan.fit("X2", data)
+    assert full["fsol"].is_cuda and torch.equal(full["fsol"], ref["fsol"]) and torch.equal(full["maps"], ref["maps"]) and torch.equal(full["reg"], ref["reg"])
+    print("RCCL2_OK")
+else:
+    assert full is None
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+@gpu
+def test_fit_sharded_over_a_two_rank_rccl_group(tmp_path):
+    """dist.fit_sharded with two processes, one GPU each, backend nccl = RCCL: interleaved 4 096-voxel blocks, ONE gather of the packed outputs
+    from device to device -- bit-equal to the unsharded fit on rank 0."""
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl2.py"
+    script.write_text(_RCCL2_WORKER % {"root": root, "pkg": PKG})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29300 + os.getpid() % 200)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+                        str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and "RCCL2_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
