@@ -69,12 +69,37 @@ def host_cores():
     return int(os.environ.get("MET2_CPU_THREADS", n))
 
 
-def source_sha(files=("met2_hip.hip", "fit_kernel.hpp", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp")):
+def source_sha(files=("met2_hip.hip", "fit_kernel.hpp", "nnls_wave.hpp", "nnls_big.hpp", "objectives.hpp", "wave_ops.hpp")):
     """Digest of the kernel sources: counter files under profiles/ are only quoted while they describe this build."""
     h = hashlib.sha256()
     for f in files:
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6       # AMD Instinct MI355X data sheet, peak FP64 vector; = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (not in the local guides)
+KERNEL_METHOD_ID = {"NNLS": 0, "T2SPARC": 1, "X2": 2, "L_curve": 3, "GCV": 6, "BayesReg": 5}      # fit_kernel<METHOD, NB, SECOND> (GCV: the low-rank form)
+
+
+def kernel_resources(method, nb):
+    """Registers and spills of the dominant fit kernel from the newest profiles/*_kernel_resource_usage.csv whose `# src_sha` line matches the
+    sources this run was built from (scripts/resource_usage.py regenerates it without a GPU); None otherwise."""
+    import glob
+    want = "void fit_kernel<%d, %d, false>(FitArgs)" % (KERNEL_METHOD_ID.get(method, -1), nb)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_resource_usage.csv")), reverse=True):
+        try:
+            lines = open(f).read().splitlines()
+            sha = [l.split(":", 1)[1].strip() for l in lines if l.startswith("# src_sha:")]
+            if not sha or sha[0] != source_sha():
+                continue
+            for l in lines:
+                if l.startswith('"' + want + '"'):
+                    v = [int(x) for x in l.rsplit('"', 1)[1].strip(", ").split(",")]
+                    return {"file": "profiles/" + os.path.basename(f), "vgprs": v[0], "agprs": v[1], "sgprs": v[2], "sgpr_spills": v[3], "vgpr_spills": v[4],
+                            "scratch_bytes_per_lane": v[5], "waves_per_simd": v[6]}
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(method, pen, brute, data_cpu, nte, nt2, T2s, T1s, alphas, lam_grid, cores, seconds=15.0):
@@ -329,11 +354,116 @@ def tv_main(args, rank, local_rank, world):
     return 0
 
 
+def host_driver_main(args):
+    """--driver host: ONE process drives N devices through the C ABI's host entry (met2_fit_host: one plan per device, one host thread per
+    plan inside the call, the voxel list dealt in runs of 4 096 voxels, every device's copies over its own PCIe link, no collective) -- the shape
+    of the reference's single Python process (motor:427-441).  Host arrays in PINNED memory in and out; `value` is host-to-host wall clock, so
+    PCIe is inside it (the torch.distributed driver's `value` is device-resident).  weak: a volume of N x the config's voxels; strong: one volume."""
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    host_mod = importlib.import_module(PKG + ".host")
+    cfg = dict(CONFIGS[args.config])
+    variant = False
+    for k, v in (("method", args.method), ("penalty", args.penalty), ("nte", args.nte), ("nt2", args.nt2), ("fa", args.fa)):
+        if v and v != cfg[k]:
+            cfg[k] = v; variant = True
+    if args.dims:
+        d = tuple(int(v) for v in args.dims.split(","))
+        variant = variant or d != cfg["dims"]
+        cfg["dims"] = d
+    N = args.gpus
+    share = os.environ.get("MET2_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < N and not share:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run fewer devices than asked\n" % (N, ndev))
+        return 3
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    devices = [0] * N if share else list(range(N))
+    nx, ny, nz = cfg["dims"]
+    nte, nt2, method, pen = cfg["nte"], cfg["nt2"], cfg["method"], cfg["penalty"]
+    strong = args.scaling == "strong"
+    nvox = nx * ny * nz * (1 if strong else N)
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    brute = cfg["fa"] == "brute-force"
+    alphas = np.linspace(90.0, 180.0, 91) if brute else np.array([150.0])
+    plans = []
+    t0 = time.perf_counter()
+    for dv in devices:
+        pl = pkg.Met2Plan(nte, nt2, alphas.shape[0], device=dv)
+        pl.build_dictionary_epg(T2s, T1s, 10.0, alphas, 3000.0).set_penalty(pen, T2s).set_t2_grid(T2s)
+        plans.append(pl)
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+    dict_build_ms = 1e3 * (time.perf_counter() - t0) / N
+    # the volume, generated on device 0 in pieces of the config's size and kept in pinned host memory
+    host = torch.empty((nvox, nte), dtype=torch.float64, pin_memory=True)
+    per = nx * ny * nz
+    for i in range(nvox // per):
+        d_i, _, _ = synth.make_voxels(per, nte=nte, seed=20260102 + i, fa_deg=150.0, fa_values=alphas if brute else None, device="cuda:0")
+        host[i * per:(i + 1) * per].copy_(d_i)
+        del d_i
+    torch.cuda.synchronize(0)
+    pin = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True).numpy()
+    outs = {"fsol": pin((nvox, nt2)), "sig": pin((nvox, nte)), "reg": pin((nvox,)), "lam": pin((nvox,)), "maps": pin((6, nvox)),
+            "status": pin((nvox,), torch.int32), "fa_index": pin((nvox,))}
+    src = host.numpy()
+    chunk = int(os.environ.get("MET2_BENCH_HOST_CHUNK", "0"))
+
+    def step():
+        return host_mod.fit_host(plans, method, src, estimate_fa=bool(brute), chunk=chunk, want_lambda=True, out=outs)
+
+    for _ in range(args.warmup):
+        step()
+    plan_ms = []; kernel_ms = []; second_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        plan_ms.append(res["plan_ms"].copy())
+        kernel_ms.append([pl.last_kernel_ms() for pl in plans]); second_ms.append([pl.last_second_pass_ms() for pl in plans])
+    dt = time.perf_counter() - t0
+    pm = np.mean(plan_ms, axis=0)
+    fitted = int((res["status"] > 0).sum())
+    bpv = BYTES_PER_VOXEL.get((nte, nt2), 8 * (2 * nte + nt2) + 65)
+    achieved = fitted * bpv * args.steps / dt / 1e9
+    moved = nvox * (8 * nte + 8 * (nt2 + nte + 2 + 6) + 4 + 8)
+    workload = "%s: synthetic %s%dx%dx%d volume, nTE=%d, nT2=%d, reg_method=%s, reg_matrix=%s, %s" % (
+        ("configs[%d]" % args.config) if not variant else "variant of configs[%d]" % args.config, ("%d x " % N) if (not strong and N > 1) else "", nx, ny, nz, nte, nt2, method, pen,
+        "FA brute-force over 91 flip angles" if brute else "single FA (150 deg)")
+    line = {
+        "metric": "voxels/sec (whole node) at nTE=32, nT2=60; max |MWF-ref|",
+        "value": nvox * args.steps / dt, "unit": "voxels/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "driver": "host: one process, met2_fit_host with one plan per device (C ABI 6), pinned host arrays in and out",
+                   "voxels": nvox, "fitted_voxels": fitted, "devices": devices, "ranks_seen": 1, "backend": None,
+                   "sharding": "runs of 4096 voxels dealt round-robin to the plans, blocks of %s voxels per DMA" % (chunk or "the library's default number of"),
+                   "collective": None, "host_bytes_moved_per_step": moved},
+        "dict_build_ms": dict_build_ms,
+        "host_driver": {"plan_ms_per_device": [float(v) for v in pm], "plan_ms_min": float(pm.min()), "plan_ms_max": float(pm.max()),
+                        "plan_ms_spread": float((pm.max() - pm.min()) / pm.max()) if pm.max() > 0 else 0.0,
+                        "last_block_kernel_ms_per_device": [float(v) for v in np.mean(kernel_ms, axis=0)],
+                        "last_block_spill_kernel_ms_per_device": [float(v) for v in np.mean(second_ms, axis=0)],
+                        "pcie_GBps_whole_job": moved * args.steps / dt / 1e9,
+                        "note": "plan_ms: wall ms of every plan's host thread inside the call (uploads, FA step, fits, downloads of its share); "
+                                "value is host-to-host, PCIe inside"},
+        "roofline": {"bound": "hbm", "kernel": "fit_kernel<%s>" % method, "achieved": achieved, "peak": HBM_PEAK_GBPS * N, "unit": "GB/s",
+                     "frac": achieved / (HBM_PEAK_GBPS * N), "traffic": None, "kernel_ms": None, "bytes_per_voxel": bpv,
+                     "note": "algorithmic bytes of the fitted voxels over the host-to-host wall time of the whole call (all devices); the kernel's own "
+                             "roofline is in the default driver's line"},
+    }
+    print(json.dumps(line), flush=True)
+    for pl in plans:
+        pl.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", type=str, default="fit", choices=["fit", "tv"],
                     help="fit (default): BASELINE.json's metric; tv: the driver's TV denoising step on a phantom of the config's shape")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--driver", type=str, default="dist", choices=["dist", "host"],
+                    help="dist (default): one process per GPU (torch.distributed / RCCL), device-resident volume, one gather; host: ONE process, "
+                         "met2_fit_host with one plan per device on pinned host arrays (the reference's single-process shape), no collective")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
@@ -359,6 +489,11 @@ def main():
     if args.gpus > 1:       # the CPU baseline and the host-to-host leg are rank 0's alone (15-25 s with N - 1 GPUs idle): single-GPU runs report them
         args.no_cpu_baseline = not args.cpu_baseline
         args.no_end_to_end = not args.end_to_end
+
+    if args.driver == "host":                # one process for all devices: nothing is spawned, and nothing has touched a GPU before this point
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--driver host is ONE process for all devices: start it plainly, not under torch.distributed.run")
+        sys.exit(host_driver_main(args))
 
     # ---- N > 1 without a torchrun environment: this process only starts the ranks (no GPU call before this point)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -536,7 +671,7 @@ def main():
         # counters (HBM bytes from FETCH/WRITE_SIZE, SQ instruction counts) come from separate rocprofv3 --pmc passes of this
         # very command, stored by scripts/collect_pmc.py with the digest of the kernel sources they were taken on; they are
         # quoted only while that digest matches the sources this run was built from
-        traffic = None; valu = None; pmc_note = "no counter file for this workload"
+        traffic = None; valu = None; ent = None; pmc_note = "no counter file for this workload"
         key = "config%d" % args.config
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
@@ -576,6 +711,31 @@ def main():
                          "kernel_ms": kms, "second_pass_ms": float(np.mean(pass2_ms)), "spill_voxels": spill_voxels, "bytes_per_voxel": bpv, "counters": pmc_note,
                          "note": "fp64 VALU-issue-bound active-set iteration, not HBM-bound (DESIGN.md section 6)"},
         }
+        # ---- the roofline that binds: fp64 vector issue.  Counter-derived numbers are quoted only while the counter file describes this build
+        # (sha-gated like `traffic`); k and the launch's waves per SIMD are measured live.
+        info = plan.launch_info(method)
+        waves_per_simd = info["block"] // 64 / 4.0
+        mean_k = plan.last_mean_k(fitted)
+        fp = {"bound": "fp64 vector issue", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "peak_source": "AMD Instinct MI355X data sheet, peak FP64 vector (= 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz); not in /opt/skills/guides",
+              "achieved": None, "frac": None, "fp64_share_of_valu_insts": None, "simd_busy_frac": None,
+              "waves_per_simd_launched": waves_per_simd, "mean_final_passive_set_k": mean_k, "live_lane_frac_position_phases": mean_k / 64.0,
+              "registers": kernel_resources(method, 2 if nt2 > 64 else 1) or "no profiles/*_kernel_resource_usage.csv for these sources (python3 scripts/resource_usage.py)",
+              "counters": pmc_note,
+              "note": "achieved = (2 FMA + MUL + ADD fp64 instructions) x 64 lanes / kernel time: ISSUED lanes, of which about live_lane_frac carry a passive bin in the "
+                      "position-indexed phases; simd_busy = SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES"}
+        try:
+            if ent is not None and ent.get("src_sha") == source_sha() and ent.get("voxels") == nvox and ent.get("valu_fma_f64") is not None:
+                flops = 64.0 * (2.0 * ent["valu_fma_f64"] + ent.get("valu_mul_f64", 0.0) + ent.get("valu_add_f64", 0.0))
+                fp["achieved"] = flops / (kms * 1e-3) / 1e12
+                fp["frac"] = fp["achieved"] / FP64_VECTOR_PEAK_TFLOPS
+                f64 = ent["valu_fma_f64"] + ent.get("valu_mul_f64", 0.0) + ent.get("valu_add_f64", 0.0) + ent.get("valu_trans_f64", 0.0)
+                fp["fp64_share_of_valu_insts"] = f64 / ent["valu_insts_per_launch"]
+                if ent.get("sq_wave_cycles"):
+                    fp["simd_busy_frac"] = ent["sq_active_inst_valu"] * waves_per_simd / ent["sq_wave_cycles"]
+        except Exception:
+            pass
+        line["roofline_fp64"] = fp
         if multi:
             line["multi_gpu"] = multi
         if valu:

@@ -24,7 +24,8 @@ struct SortBufs {
     int *chunk_start;  // [nfa+1]
     int *queue;        // [1]
     int *xq;           // [8]  one queue cursor per XCD (fit kernel)
-    int *err;          // [3]  [0] bit0: FA index out of range; [1], [2]: tail and head of the spill-over queue
+    int *err;          // [4]  [0] bit0: FA index out of range; [1], [2]: tail and head of the spill-over queue; [3]: sum over the fitted voxels of the
+                       //      passive-set size of their final solve (bench.py: the live-lane fraction k / 64 of the position-indexed phases, measured)
     int *ovf;          // [nvox] the spill-over queue: voxels whose passive set outgrew the wave's LDS region
 };
 
@@ -784,6 +785,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         A.reg[v] = regv;
         if (A.lam) A.lam[v] = lamv;
         if (A.status) A.status[v] = stat;
+        if (BIG || !(st.itmax_hit & 2)) atomicAdd(A.sb.err + 3, st.k);      // (a queued voxel is counted by the spill-over kernel)
     }
     return !BIG && (st.itmax_hit & 2) != 0;                     // the set outgrew the wave's LDS region (the outputs just written carry MET2_ST_KOVERFLOW): the caller queues the voxel for the spill-over kernel
 }

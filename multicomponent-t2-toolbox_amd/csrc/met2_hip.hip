@@ -1030,8 +1030,9 @@ struct met2_plan {
     double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
     double *dBig = nullptr; int64_t cap_big = 0;          // the waves' spill-over slots: factor columns beyond the LDS capacity (nnls_big.hpp), grown on demand
     int last_spill = 0;                                   // voxels of the last finished fit(s) that used them
+    int64_t last_ksum = 0;                                // sum of the final passive-set sizes of the last finished fit's voxels
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
-    int *hErr = nullptr;                                  // pinned [2]: the FA-range error word of an enqueued fit lands here, and its spill-over count
+    int *hErr = nullptr;                                  // pinned [4]: the FA-range error word of an enqueued fit lands here, its spill-over count (queue tail, head) and sum of final k
     bool err_pending = false;
     hipStream_t err_stream = nullptr;                     // the stream the fits since the last finish were enqueued on (one plan serves one stream at a time)
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
@@ -1572,8 +1573,8 @@ int met2_plan_create(met2_plan **out, int32_t n_te, int32_t n_t2, int32_t n_fa, 
     HIPCHK(hipMalloc(&p->dT2, sizeof(double) * 128));
     HIPCHK(hipMalloc(&p->dSmall, sizeof(int) * (4 * (size_t)(n_fa + 1) + 16)));
     HIPCHK(hipMalloc(&p->dSeed, sizeof(SeedRec) * 4 * (size_t)n_fa));
-    HIPCHK(hipHostMalloc((void **)&p->hErr, 2 * sizeof(int), hipHostMallocDefault));
-    p->hErr[0] = p->hErr[1] = 0;
+    HIPCHK(hipHostMalloc((void **)&p->hErr, 4 * sizeof(int), hipHostMallocDefault));
+    p->hErr[0] = p->hErr[1] = p->hErr[2] = p->hErr[3] = 0;
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
     HIPCHK(hipEventCreate(&p->ev2));
@@ -1836,6 +1837,7 @@ int met2_plan_finish(met2_plan *p, void *stream)
         p->err_pending = false;
         const int herr = p->hErr[0];
         p->last_spill = p->hErr[1];
+        p->last_ksum = p->hErr[3];
         p->hErr[0] = 0;
         if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
     }
@@ -2059,7 +2061,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     }
     // FA index range errors (IndexError in the reference): the error word lands in the plan's pinned host word; the blocking entries
     // wait for it here, an enqueued fit leaves it to met2_plan_finish (errors of several enqueued fits accumulate: the kernel ORs)
-    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));      // the error word and the spill-over count (the queue's tail)
+    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, 4 * sizeof(int), hipMemcpyDeviceToHost, s));      // the error word, the spill-over count (the queue's tail, head) and the sum of k
     p->err_pending = true; p->err_stream = s;
     if (!sync) return MET2_OK;
     return met2_plan_finish(p, stream);
@@ -2250,6 +2252,13 @@ int met2_plan_last_spill_count(met2_plan *p, int64_t *count)
 {
     if (!p || !count) return fail(MET2_E_INVALID, "NULL argument");
     *count = p->last_spill;
+    return MET2_OK;
+}
+
+int met2_plan_last_mean_k(met2_plan *p, int64_t fitted, double *mean_k)
+{
+    if (!p || !mean_k) return fail(MET2_E_INVALID, "NULL argument");
+    *mean_k = fitted > 0 ? (double)p->last_ksum / (double)fitted : 0.0;
     return MET2_OK;
 }
 

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = "multicomponent-t2-toolbox_amd"
 
 
-def source_sha(files=("met2_hip.hip", "fit_kernel.hpp", "nnls_wave.hpp", "objectives.hpp", "wave_ops.hpp")):
+def source_sha(files=("met2_hip.hip", "fit_kernel.hpp", "nnls_wave.hpp", "nnls_big.hpp", "objectives.hpp", "wave_ops.hpp")):
     h = hashlib.sha256()
     for f in files:
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())

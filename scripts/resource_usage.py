@@ -6,7 +6,16 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRCS = [os.path.join(ROOT, "multicomponent-t2-toolbox_amd", "csrc", f) for f in ("met2_hip.hip", "met2_fit_x2_nb1.hip", "met2_fit_x2_nb2.hip", "met2_fit_x2_second.hip", "met2_fit_nnls_lcurve.hip",
                                                                                   "met2_fit_gcv.hip", "met2_fit_bayes.hip", "met2_tv.hip")]
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+
+
+def source_sha(files=("met2_hip.hip", "fit_kernel.hpp", "nnls_wave.hpp", "nnls_big.hpp", "objectives.hpp", "wave_ops.hpp")):
+    """the digest bench.py gates the file on (same list as bench.py / collect_pmc.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "multicomponent-t2-toolbox_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def demangle(n):
@@ -24,6 +33,7 @@ def main():
         s += open(asm).read()
     with open(os.path.join(ROOT, "profiles", TAG + "_kernel_resource_usage.csv"), "w") as f:
         f.write("# hipcc --offload-arch=gfx950 -O3 -mllvm -disable-machine-licm -Rpass-analysis=kernel-resource-usage (scripts/resource_usage.py), sources of the current evidence\n")
+        f.write("# src_sha: %s\n" % source_sha())
         f.write("# kernel, VGPRs, AGPRs, SGPRs, SGPR spills, VGPR spills, scratch B/lane, occupancy waves/SIMD\n")
         for b in blocks:
             name = b.split()[0]
