@@ -22,8 +22,9 @@ anything touches the GPU -- relays the child's JSON line and exits with its code
 a silent 1-rank run.
 
 Besides `value` (region (i) of SURVEY.md section 8d: device-resident in -> device-resident out) the line carries
-`dict_build_ms` (region (ii): EPG dictionary + Gram matrices + seeds, once per run) and `end_to_end` (region (iii): pinned host
-volume -> chunked H2D -> fit -> D2H of every output on two streams, rank 0's volume).
+`dict_build_ms` (region (ii): EPG dictionary + Gram matrices + seeds, once per run) and `end_to_end` (region (iii): host volume ->
+blocks H2D -> fit -> D2H of every output through the C ABI's host entry met2_fit_host, rank 0's volume).
+  --driver host: ONE process drives all N devices through that entry (pinned host arrays in and out); see host_driver_main.
 
 Prints ONE JSON line on rank 0.
 """
@@ -214,48 +215,39 @@ def plumbing_main(args, rank, world, mdist):
 
 
 def end_to_end(plan, pkg, method, data, brute, chunk_vox=262144, reps=3):
-    """Region (iii) of SURVEY.md section 8d on this rank: the volume in PINNED host memory -> chunked H2D -> [FA estimation] -> fit ->
-    D2H of fsol, Est_Signal, reg_param and the six maps into pinned host buffers, copies and kernels overlapped on two streams
-    (motor.fit_host_pipeline, the pipeline recon_met2_arrays uses)."""
-    motor = importlib.import_module(PKG + ".motor")
+    """Region (iii) of SURVEY.md section 8d on this rank, through the C ABI's host entry (met2_fit_host: numpy arrays in and out, the block
+    pipeline inside the library, no torch on the call path): the volume in host memory -> blocks H2D -> [FA estimation] -> fit -> D2H of fsol,
+    Est_Signal, reg_param and the six maps, copies and kernels overlapped on three streams.  Once with every array in PINNED memory (the DMA
+    engines reach the caller's arrays themselves), once with pageable numpy arrays (staged by the library under the fits)."""
+    host_mod = importlib.import_module(PKG + ".host")
     host = torch.empty(data.shape, dtype=torch.float64, pin_memory=True)
     host.copy_(data)
     torch.cuda.synchronize()
-    best = None
-    out = None
-    first = None
-    for _ in range(reps + 1):                       # the first pass also pins the output buffers; the later ones write them again
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out = motor.fit_host_pipeline(plan, method, host, fa_method="brute-force" if brute else None, chunk=chunk_vox, out=out)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if first is None:
-            first = dt
-        else:
-            best = dt if best is None else min(best, dt)
-    nbytes = host.numel() * 8 + sum(int(t.numel()) * t.element_size() for t in out.values() if torch.is_tensor(t))
-    # the same through the C ABI's own host entry (met2_fit_host, ABI 5: numpy arrays in and out, the pipeline inside the library, no torch
-    # on the call path): once with every array in pinned memory (used in place), once with pageable numpy arrays (staged by the library)
-    c_abi = {}
-    try:
-        host_mod = importlib.import_module(PKG + ".host")
-        pinned_out = {k: out[k].numpy() for k in ("fsol", "sig", "reg", "maps", "status", "fa_index")}
-        for label, src, outs in (("pinned", host.numpy(), pinned_out), ("pageable", np.array(host.numpy()), None)):
-            b = None
-            for i in range(reps + 1):
-                t0 = time.perf_counter()
-                outs = host_mod.fit_host(plan, method, src, estimate_fa=bool(brute), chunk=chunk_vox, out=outs)
-                dt = time.perf_counter() - t0
-                if i:
-                    b = dt if b is None else min(b, dt)
-            same = bool(np.array_equal(outs["fsol"], out["fsol"].numpy(), equal_nan=True) and np.array_equal(outs["maps"], out["maps"].numpy(), equal_nan=True))
-            c_abi[label] = {"ms": 1e3 * b, "voxels_per_s": data.shape[0] / b, "bit_equal_to_the_python_pipeline": same}
-    except Exception as e:      # noqa: BLE001
-        c_abi = {"error": repr(e)[:300]}
-    return {"c_abi_met2_fit_host": c_abi, "ms": 1e3 * best, "first_call_ms": 1e3 * first, "voxels_per_s": data.shape[0] / best, "chunk_voxels": chunk_vox, "host_bytes_moved": nbytes,
-            "pcie_GBps": nbytes / best / 1e9,
-            "includes": "pinned host volume -> H2D -> %sfit + metrics -> D2H of fsol, Est_Signal, reg_param, maps (two streams, chunks of %d voxels)"
+    nvox, nte = data.shape
+    pin = lambda shape, dt=torch.float64: torch.empty(shape, dtype=dt, pin_memory=True).numpy()
+    pinned_out = {"fsol": pin((nvox, plan.n_t2)), "sig": pin((nvox, nte)), "reg": pin((nvox,)), "maps": pin((6, nvox)), "status": pin((nvox,), torch.int32),
+                  "fa_index": pin((nvox,))}
+    res = {}
+    ref = None
+    for label, src, outs in (("pinned", host.numpy(), pinned_out), ("pageable", np.array(host.numpy()), None)):
+        b = None; first = None
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            outs = host_mod.fit_host(plan, method, src, estimate_fa=bool(brute), chunk=chunk_vox, out=outs)
+            dt = time.perf_counter() - t0
+            if i == 0:
+                first = dt
+            else:
+                b = dt if b is None else min(b, dt)
+        if ref is None:
+            ref = outs
+        res[label] = {"ms": 1e3 * b, "first_call_ms": 1e3 * first, "voxels_per_s": nvox / b,
+                      "bit_equal_to_the_pinned_run": bool(np.array_equal(outs["fsol"], ref["fsol"], equal_nan=True) and np.array_equal(outs["maps"], ref["maps"], equal_nan=True))}
+    nbytes = host.numel() * 8 + sum(int(a.nbytes) for a in pinned_out.values())
+    best = res["pinned"]["ms"] * 1e-3
+    return {"c_abi_met2_fit_host": res, "ms": res["pinned"]["ms"], "first_call_ms": res["pinned"]["first_call_ms"], "voxels_per_s": res["pinned"]["voxels_per_s"],
+            "chunk_voxels": chunk_vox, "host_bytes_moved": nbytes, "pcie_GBps": nbytes / best / 1e9,
+            "includes": "host volume -> H2D -> %sfit + metrics -> D2H of fsol, Est_Signal, reg_param, maps (met2_fit_host: three streams, blocks of %d voxels)"
                         % ("brute-force FA -> " if brute else "", chunk_vox)}
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of build-time switches (run on the GPU box):  [ONLY=<method number>] [BENCH="--config 3"] scripts/dev_ab.sh "-DFOO=0" "-DFOO=1" ...
+# A/B of build-time switches (run on the GPU box):  [ONLY=<method number>] [BENCH="--config 3"] scripts/dev/ab.sh "-DFOO=0" "-DFOO=1" ...
 # Each argument is a set of extra defines; the single-method library (-DMET2_ONLY, default 2 = X2) is rebuilt for each and bench.py's
 # kernel time and parity block printed.  The tree's library is left at the LAST build: rebuild before anything else.
 cd "$(dirname "$0")/.."

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 A/B lines (one GPU): kernel ms, second-pass ms and spill-over voxels of the workloads the single-launch fit is judged on.
-#   bash scripts/dev_ab5.sh [label]      (MET2_TWO_PASS=1 in the environment: the two-launch capacity ladder of rounds 1-4)
+#   bash scripts/dev/ab5.sh [label]      (MET2_TWO_PASS=1 in the environment: the two-launch capacity ladder of rounds 1-4)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 L=${1:-ab}
 run() {

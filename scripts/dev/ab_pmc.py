@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """A/B of build-time switches with hardware counters on configs[1] (run ON THE GPU BOX):
-    python3 scripts/dev_ab_pmc.py "-DMET2_REORDER=0" "-DMET2_REORDER=1"
+    python3 scripts/dev/ab_pmc.py "-DMET2_REORDER=0" "-DMET2_REORDER=1"
 For every set of defines: rebuild the X2-only library, one plain bench run (kernel ms) and one rocprofv3 --pmc pass (SQ instruction
 and wait counters of the dominant fit_kernel dispatch).  Prints one line per build."""
 import csv, glob, json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CTRS = os.environ["CTRS"].split() if os.environ.get("CTRS") else ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_LDS_IDX_ACTIVE"]
 bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
 for defs in sys.argv[1:]:

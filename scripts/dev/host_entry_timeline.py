@@ -1,5 +1,5 @@
 """met2_fit_host on configs[1]'s volume (pinned arrays, one plan, default blocks) three times, for a rocprofv3 --kernel-trace
---memory-copy-trace timeline (scripts/probes/timeline_report.py digests the last call)."""
+--memory-copy-trace timeline (scripts/dev/timeline_report.py digests the last call)."""
 import importlib, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

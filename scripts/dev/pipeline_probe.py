@@ -1,7 +1,7 @@
 """One timing table for the reference's example pipeline (example_script_run_MET2_preproc_and_recon.sh: --denoise TV, FA_method spline, FA_smooth
 yes, X2 / L2) on a 128 x 128 x 64 x 32 head phantom: every device step on device-resident tensors (HIP events, best of three), and the wall
 clock of whole recon_met2_arrays calls from a pageable numpy volume with each denoising option.
-    python3 scripts/dev_pipeline_probe.py [nx,ny,nz]"""
+    python3 scripts/dev/pipeline_probe.py [nx,ny,nz]"""
 import importlib, json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -1,5 +1,5 @@
 // Probe: relative error of v_rsq_f64 / v_rcp_f64 raw, after one and after two Newton steps (gfx950).
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/rsq_probe scripts/probes/rsq_precision.hip && /tmp/rsq_probe
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/rsq_probe scripts/dev/rsq_precision.hip && /tmp/rsq_probe
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

@@ -3,7 +3,7 @@ the 65 536-voxel reference fixture and the 13-voxel fail set against the REFEREN
 refined evaluation (status bit 64)."""
 import importlib, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import parity_report as pr

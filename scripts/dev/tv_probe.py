@@ -1,6 +1,6 @@
 """GPU probe of the TV denoiser (met2_tv_chambolle): wall time of the whole step on a 128 x 128 x 64 x 32 phantom, iteration counts per
 echo, time per Chambolle iteration and the HBM rate its 56 algorithmic bytes per (voxel, echo) amount to.
-    python3 scripts/dev_tv_probe.py [nx ny nz nt] [--fortran]"""
+    python3 scripts/dev/tv_probe.py [nx ny nz nt] [--fortran]"""
 import importlib
 import json
 import os
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 PKG = "multicomponent-t2-toolbox_amd"
 
 

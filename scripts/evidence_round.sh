@@ -31,9 +31,9 @@ fi
 if [ $STAGE = all ] || [ $STAGE = bench ]; then
   bash scripts/bench_configs.sh $TAG
   bash scripts/bench_other_methods.sh $TAG
-  python3 scripts/dev_driver_probe.py > gpurun_out/${TAG}_driver_probe.jsonl 2> gpurun_out/${TAG}_driver_probe.err
+  python3 scripts/dev/driver_probe.py > gpurun_out/${TAG}_driver_probe.jsonl 2> gpurun_out/${TAG}_driver_probe.err
   python3 bench.py --workload tv > gpurun_out/${TAG}_tv_bench.json 2> gpurun_out/${TAG}_tv_bench.err
-  python3 scripts/dev_pipeline_probe.py > gpurun_out/${TAG}_pipeline_timing.jsonl 2> gpurun_out/${TAG}_pipeline_timing.err
+  python3 scripts/dev/pipeline_probe.py > gpurun_out/${TAG}_pipeline_timing.jsonl 2> gpurun_out/${TAG}_pipeline_timing.err
 fi
 if [ $STAGE = all ] || [ $STAGE = parity ]; then
   python3 tests/tools/parity_report.py --out gpurun_out/parity_${TAG}.json > gpurun_out/parity_${TAG}.log 2>&1

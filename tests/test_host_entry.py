@@ -310,26 +310,20 @@ def test_driver_with_a_device_list_equals_the_default_driver(pkg, order, denoise
     TE = 10.0 * np.arange(1, 33)
     fa_given = fa.cpu().numpy().reshape(dims) if fa_method == "given" else None
     method = "brute-force" if fa_method == "given" else fa_method
+    from tools import torch_pipeline as tp                             # the torch pipeline of rounds 3-4 (retired from the product): the comparator
     keep = motor.PIPELINE_CHUNK
     try:
         motor.PIPELINE_CHUNK = 700
-        motor.DRIVER_THROUGH_C_ABI = False                          # the torch pipeline (fit_host_pipeline) on one device
-        ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given)
-        motor.DRIVER_THROUGH_C_ABI = True
+        ref = tp.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given, chunk=700)
         got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given, devices=devices)
         dflt = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, fa_index=fa_given)
     finally:
         motor.PIPELINE_CHUNK = keep
-        motor.DRIVER_THROUGH_C_ABI = True
     assert np.array_equal(dflt["fsol_4D"], ref["fsol_4D"], equal_nan=True) and np.array_equal(dflt["FA"], ref["FA"])
     for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
         assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), k
     if denoise == "TV":                                             # the file-level driver saves the denoised volume (motor:302-303)
-        motor.DRIVER_THROUGH_C_ABI = False
-        try:
-            a = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
-        finally:
-            motor.DRIVER_THROUGH_C_ABI = True
+        a = tp.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
         b = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True, devices=devices)
         assert np.array_equal(a["data_prepared"], b["data_prepared"]) and np.array_equal(a["MWF"], b["MWF"], equal_nan=True)
 

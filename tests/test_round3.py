@@ -219,7 +219,7 @@ def test_chunked_host_pipeline_equals_the_one_shot_fit(pinned):
     # blocking fit of the whole list: bit-equal in every output, for pinned and for pageable host memory, ragged last chunk
     import torch
     pkg = importlib.import_module(PKG)
-    motor = importlib.import_module(PKG + ".motor")
+    from tools import torch_pipeline as motor             # (the torch pipeline: retired from the product in round 5, kept as the comparator)
     synth = importlib.import_module(PKG + ".synth")
     nte, nt2, nvox = 32, 60, 10007
     T2s = synth.t2_grid(nt2)
@@ -275,13 +275,8 @@ def test_singular_penalty_runs_unseeded_and_fits_like_the_oracle(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("order,fa_method", [("C", "brute-force"), ("F", "brute-force"), ("F", "spline")])
 def test_driver_pipeline_equals_one_shot(order, fa_method):
-    # (the torch pipeline of the driver: since late round 4 the default driver goes through met2_fit_host -- tests/test_host_entry.py compares the two)
-    motor = importlib.import_module(PKG + ".motor")
-    motor.DRIVER_THROUGH_C_ABI = False
-    try:
-        _test_driver_pipeline_equals_one_shot_impl(order, fa_method)
-    finally:
-        motor.DRIVER_THROUGH_C_ABI = True
+    # (the torch pipeline of the driver, tests/tools/torch_pipeline.py: the product's default driver goes through met2_fit_host -- tests/test_host_entry.py compares the two)
+    _test_driver_pipeline_equals_one_shot_impl(order, fa_method)
 
 
 def _test_driver_pipeline_equals_one_shot_impl(order, fa_method):
@@ -302,12 +297,8 @@ def _test_driver_pipeline_equals_one_shot_impl(order, fa_method):
     if order == "F":
         vol = np.asfortranarray(vol)
     TE = 10.0 * np.arange(1, 33)
-    keep = motor.PIPELINE_CHUNK
-    try:
-        motor.PIPELINE_CHUNK = 500                                  # 1287 voxels -> three chunks, the last one ragged
-        got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0)
-    finally:
-        motor.PIPELINE_CHUNK = keep
-    ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, return_prepared=True)
+    from tools import torch_pipeline as tp
+    got = tp.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, chunk=500)      # 1287 voxels -> three chunks, the last one ragged
+    ref = tp.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, return_prepared=True)
     for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
         assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k

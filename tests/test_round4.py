@@ -446,13 +446,8 @@ def test_bench_tv_workload_line():
 @pytest.mark.parametrize("order,denoise,smooth,fa_method", [("C", "TV", "yes", "spline"), ("F", "TV", "yes", "spline"), ("F", "NESMA", "no", "brute-force"),
                                                             ("C", "None", "yes", "brute-force"), ("F", "None", "yes", "spline")])
 def test_filtered_runs_are_chunked_on_the_device(order, denoise, smooth, fa_method):
-    # (the torch pipeline of the driver: since late round 4 the default driver goes through met2_fit_host -- tests/test_host_entry.py compares the two)
-    motor = importlib.import_module(PKG + ".motor")
-    motor.DRIVER_THROUGH_C_ABI = False
-    try:
-        _test_filtered_runs_are_chunked_on_the_device_impl(order, denoise, smooth, fa_method)
-    finally:
-        motor.DRIVER_THROUGH_C_ABI = True
+    # (the torch pipeline of the driver, tests/tools/torch_pipeline.py: the product's default driver goes through met2_fit_host -- tests/test_host_entry.py compares the two)
+    _test_filtered_runs_are_chunked_on_the_device_impl(order, denoise, smooth, fa_method)
 
 
 def _test_filtered_runs_are_chunked_on_the_device_impl(order, denoise, smooth, fa_method):
@@ -472,19 +467,8 @@ def _test_filtered_runs_are_chunked_on_the_device_impl(order, denoise, smooth, f
     if order == "F":
         vol = np.asfortranarray(vol)
     TE = 10.0 * np.arange(1, 33)
-    keep = motor.PIPELINE_CHUNK
-    try:
-        motor.PIPELINE_CHUNK = 700                                  # 2184 voxels -> four chunks, the last one ragged
-        got = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth)
-    finally:
-        motor.PIPELINE_CHUNK = keep
-    ref = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
+    from tools import torch_pipeline as tp
+    got = tp.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth, chunk=700)      # 2184 voxels -> four chunks, the last one ragged
+    ref = tp.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth, return_prepared=True)
     for k in ("fsol_4D", "Est_Signal", "reg_param", "FA_index", "FA", "MWF", "IEWF", "FWF", "T2_M", "T2_IE", "TWC"):
         assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), k
-    # ... and the switch back to the one-call path gives the same again
-    try:
-        motor.ONE_SHOT_PIPELINE = False
-        one = motor.recon_met2_arrays(vol, mask, TE, 3000.0, "X2", "L2", fa_method, 40.0, denoise=denoise, FA_smooth=smooth)
-    finally:
-        motor.ONE_SHOT_PIPELINE = True
-    assert np.array_equal(one["MWF"], got["MWF"], equal_nan=True) and np.array_equal(one["FA_index"], got["FA_index"])
