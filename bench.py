@@ -707,7 +707,9 @@ def main():
         # (sha-gated like `traffic`); k and the launch's waves per SIMD are measured live.
         info = plan.launch_info(method)
         waves_per_simd = info["block"] // 64 / 4.0
-        mean_k = plan.last_mean_k(fitted)
+        # the passive set of a voxel's final solve = its positive bins: counted on the outputs (a device-side counter cost the X2 kernel its L2-resident
+        # scratch: 112 -> 120 bytes per lane and 1.4x -> 3.5x of the algorithmic HBM bytes, profiles/r05_ab.txt)
+        mean_k = float((out["fsol"] > 0).sum().item()) / max(fitted, 1)
         fp = {"bound": "fp64 vector issue", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
               "peak_source": "AMD Instinct MI355X data sheet, peak FP64 vector (= 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz); not in /opt/skills/guides",
               "achieved": None, "frac": None, "fp64_share_of_valu_insts": None, "simd_busy_frac": None,

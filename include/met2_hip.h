@@ -338,10 +338,6 @@ int met2_plan_last_kernel_ms(met2_plan *plan, double *ms);
  * met2_plan_last_second_pass_ms: rounds 1-4 solved those voxels again in a second launch at full capacity; that ladder runs
  * only with MET2_TWO_PASS=1 in the environment (A/B test switch), otherwise this returns 0. */
 int met2_plan_last_spill_count(met2_plan *plan, int64_t *count);
-/* For reports: the mean passive-set size of the final solves of the most recent finished fit, given how many of its voxels were fitted (the
- * kernels add every fitted voxel's k to one device word).  k / 64 is the share of a wave's lanes that work in the position-indexed phases
- * of the solver (re-factorisation, substitutions, plane rotations). */
-int met2_plan_last_mean_k(met2_plan *plan, int64_t fitted_voxels, double *mean_k);
 int met2_plan_last_second_pass_ms(met2_plan *plan, double *ms);
 
 /* Launch geometry of the solver kernel (for reports): workgroups, threads per workgroup,

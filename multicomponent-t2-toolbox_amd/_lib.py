@@ -26,7 +26,7 @@ SYMBOLS = ["met2_default_options", "met2_abi_version", "met2_device_count", "met
            "met2_plan_destroy", "met2_plan_set_options", "met2_plan_get_options", "met2_plan_build_dictionary_epg", "met2_plan_set_dictionary", "met2_plan_get_dictionary",
            "met2_plan_set_penalty", "met2_plan_set_penalty_dense", "met2_plan_get_penalty", "met2_plan_set_lambda_grid",
            "met2_plan_set_t2_grid", "met2_fit", "met2_fit_strided", "met2_fit_enqueue_strided", "met2_plan_finish", "met2_fa_bruteforce", "met2_fa_bruteforce_strided", "met2_fa_spline_select",
-           "met2_fa_spline_select_strided", "met2_roi_reduce", "met2_nesma", "met2_tv_work_bytes", "met2_tv_chambolle", "met2_tv_last_timing", "met2_smooth_separable", "met2_metrics", "met2_plan_last_kernel_ms", "met2_plan_last_second_pass_ms", "met2_plan_last_spill_count", "met2_plan_last_mean_k",
+           "met2_fa_spline_select_strided", "met2_roi_reduce", "met2_nesma", "met2_tv_work_bytes", "met2_tv_chambolle", "met2_tv_last_timing", "met2_smooth_separable", "met2_metrics", "met2_plan_last_kernel_ms", "met2_plan_last_second_pass_ms", "met2_plan_last_spill_count",
            "met2_plan_launch_info", "met2_plan_gcv_form", "met2_plan_get_shape", "met2_fit_host", "met2_plan_attach_fa_spline", "met2_host_trim"]
 
 
@@ -71,7 +71,6 @@ def lib():
         L.met2_plan_last_kernel_ms.argtypes = [vp, _dp]
         L.met2_plan_last_second_pass_ms.argtypes = [vp, _dp]
         L.met2_plan_last_spill_count.argtypes = [vp, C.POINTER(C.c_int64)]
-        L.met2_plan_last_mean_k.argtypes = [vp, C.c_int64, _dp]
         L.met2_plan_gcv_form.argtypes = [vp, C.POINTER(C.c_int32), _dp]
         L.met2_plan_launch_info.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.met2_plan_get_shape.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

@@ -24,8 +24,7 @@ struct SortBufs {
     int *chunk_start;  // [nfa+1]
     int *queue;        // [1]
     int *xq;           // [8]  one queue cursor per XCD (fit kernel)
-    int *err;          // [4]  [0] bit0: FA index out of range; [1], [2]: tail and head of the spill-over queue; [3]: sum over the fitted voxels of the
-                       //      passive-set size of their final solve (bench.py: the live-lane fraction k / 64 of the position-indexed phases, measured)
+    int *err;          // [3]  [0] bit0: FA index out of range; [1], [2]: tail and head of the spill-over queue
     int *ovf;          // [nvox] the spill-over queue: voxels whose passive set outgrew the wave's LDS region
 };
 
@@ -44,7 +43,12 @@ struct FitArgs {
     int method, nlam, maxfun;
     double x2_factor, t2sparc_lambda, xtol;
     double cut_m, cut_ie;
-    double lam_lo, lam_hi;                // the interval of the method's lambda search (met2_options: x2_lo .. bayes_hi)
+    double lam_lo, lam_hi;                // the interval of the method's lambda search (met2_options: x2_lo .. bayes_hi).  Read by the BIG = true
+                                          // instance of the voxel routine only: the fit kernels' own instance carries the reference's literals (with the
+                                          // interval in registers fit_kernel<X2, 1> went from 112 to 140 bytes of scratch per lane -- out of the L2s:
+                                          // 1.4x -> 2.8x of the algorithmic HBM bytes), and a plan with other intervals sends EVERY voxel through the
+                                          // spill-over kernel (all_queued)
+    int all_queued;                       // the spill-over kernel takes every fitted voxel (the sorted list sb.perm), not the queue
     double log_detL;
     const double *Dfa;    // [nfa][m][n]
     const double *Bfa;    // [nfa][n][n]
@@ -592,7 +596,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             best_sse = last_sse;
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
-        }, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag, nref);
+        }, BIG ? A.lam_lo : 0.0, BIG ? A.lam_hi : 10.0, A.xtol, A.maxfun, flag, nref);
         if (MET2_TIE_GUARD == 2 && nref) stat |= 64 | (nref & 0x1f00);
 #else
         double lam = fminbound_dev([&](double x) {
@@ -626,7 +630,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             best_sse = last_sse;
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) { best_x[bb] = st.x[bb]; best_pos[bb] = st.pos[bb]; best_ord[bb] = st.ord[bb]; }
-        }, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag);
+        }, BIG ? A.lam_lo : 0.0, BIG ? A.lam_hi : 10.0, A.xtol, A.maxfun, flag);
 #endif
         if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
         if (lam != last_x && !(NB == 2 && (st.itmax_hit & 2))) {
@@ -714,7 +718,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             }
             ++ev;
             return bayes_objective<NB>(S, bd, st, bc, x, b, lane, tab, cholG);
-        }, []() {}, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag);
+        }, []() {}, BIG ? A.lam_lo : 1e-8, BIG ? A.lam_hi : 2.0, A.xtol, A.maxfun, flag);
         if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
         if (bc.failed) stat |= MET2_ST_CHOLFAIL;
         if (!(NB == 2 && (st.itmax_hit & 2))) solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
@@ -728,7 +732,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
             if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
             solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
             return gcv_objective<NB, METHOD == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);
-        }, []() {}, A.lam_lo, A.lam_hi, A.xtol, A.maxfun, flag);
+        }, []() {}, BIG ? A.lam_lo : 1e-8, BIG ? A.lam_hi : 10.0, A.xtol, A.maxfun, flag);
         if (flag == 1) stat |= MET2_ST_BRENT_MAXFUN;
         if (overflow) stat |= MET2_ST_KOVERFLOW;
         if (!(NB == 2 && (st.itmax_hit & 2))) solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
@@ -785,7 +789,6 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         A.reg[v] = regv;
         if (A.lam) A.lam[v] = lamv;
         if (A.status) A.status[v] = stat;
-        if (BIG || !(st.itmax_hit & 2)) atomicAdd(A.sb.err + 3, st.k);      // (a queued voxel is counted by the spill-over kernel)
     }
     return !BIG && (st.itmax_hit & 2) != 0;                     // the set outgrew the wave's LDS region (the outputs just written carry MET2_ST_KOVERFLOW): the caller queues the voxel for the spill-over kernel
 }
@@ -906,7 +909,8 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
     } else {
     // ---- the spill-over queue (written by the launch before this one): every wave takes entries until none is left
     if constexpr (METHOD < 10) {
-    const int ntail = A.sb.err[1];
+    const int ntail = A.all_queued ? A.sb.bucket_start[A.nfa] : A.sb.err[1];      // (all_queued: every fitted voxel, in the sorted list's order)
+    const int *queue = A.all_queued ? A.sb.perm : A.sb.ovf;
     FitArgs Ac = A;                                       // (a private copy for the not-inlined voxel routine)
     // The workgroup's LDS is carved for as few waves as give every queued voxel a wave of its own (this kernel's duration is the latency of its
     // slowest voxel when the queue is short, its throughput when it is long): w2 waves, each with the largest factor capacity its share holds --
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
         if (lane == 0) i = atomicAdd(A.sb.err + 2, 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= ntail) break;
-        const int64_t v = A.sb.ovf[i];
+        const int64_t v = queue[i];
         fit_voxel_spill<METHOD, NB>(&Ac, (big_lds_dp)sR, v, A.sb.key[v], wslot);
     }
     }

@@ -1030,9 +1030,8 @@ struct met2_plan {
     double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
     double *dBig = nullptr; int64_t cap_big = 0;          // the waves' spill-over slots: factor columns beyond the LDS capacity (nnls_big.hpp), grown on demand
     int last_spill = 0;                                   // voxels of the last finished fit(s) that used them
-    int64_t last_ksum = 0;                                // sum of the final passive-set sizes of the last finished fit's voxels
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
-    int *hErr = nullptr;                                  // pinned [4]: the FA-range error word of an enqueued fit lands here, its spill-over count (queue tail, head) and sum of final k
+    int *hErr = nullptr;                                  // pinned [4]: the FA-range error word of an enqueued fit lands here, and its spill-over queue's tail (= count) and head
     bool err_pending = false;
     hipStream_t err_stream = nullptr;                     // the stream the fits since the last finish were enqueued on (one plan serves one stream at a time)
     int32_t *dStatus = nullptr; int64_t cap_status = 0;   // internal status words when the caller passes none   // dSmall: hist|cursor|bucket_start|chunk_start|queue|err
@@ -1837,7 +1836,6 @@ int met2_plan_finish(met2_plan *p, void *stream)
         p->err_pending = false;
         const int herr = p->hErr[0];
         p->last_spill = p->hErr[1];
-        p->last_ksum = p->hErr[3];
         p->hErr[0] = 0;
         if (herr & 1) return fail(MET2_E_INVALID, "FA index outside the dictionary's flip-angle axis");
     }
@@ -1959,7 +1957,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     }
     // spill-over slots (nnls_big.hpp): a set that outgrows the LDS capacity of the launch goes on in place, its columns beyond the capacity in
     // the wave's slot -- one launch per fit.
-    A.big = nullptr; A.big_stride = 0;
+    A.big = nullptr; A.big_stride = 0; A.all_queued = 0;
     if (kfast && !two_pass) {
         const int stride = (col_base(p->n_t2) - col_base(g.kmax) + 15) & ~15;
         LaunchGeom gw;                                                      // sized for the widest launch of this shape (a short voxel list runs fewer waves):
@@ -1978,12 +1976,28 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     if (MET2_BAYES_TABLE > 0 && method == MET2_BAYESREG && !objgrid && p->dBtab && p->seeds_valid && p->seeds_ok && !tuning_env("MET2_NO_BAYES_TABLE", 0, 1, 0)) {
         A.btab = p->dBtab; A.nbtab = MET2_BAYES_TABLE;
     }
+    // The fit kernels carry the reference's lambda-search intervals as literals (fit_kernel.hpp: FitArgs::lam_lo); a plan whose options name other
+    // intervals runs every voxel through the spill-over kernel, whose instance of the voxel routine reads them -- correct, and slower (the solver is
+    // a function call there).
+    const bool custom_iv = !objgrid && ((method == MET2_X2 && (p->opt.x2_lo != 0.0 || p->opt.x2_hi != 10.0)) || (method == MET2_GCV && (p->opt.gcv_lo != 1e-8 || p->opt.gcv_hi != 10.0)) ||
+                                        (method == MET2_BAYESREG && (p->opt.bayes_lo != 1e-8 || p->opt.bayes_hi != 2.0)));
     HIPCHK(hipEventRecord(p->ev0, s));
     if (objgrid) { A.sig = nullptr; A.maps = nullptr; A.lam = nullptr; }
-    rc = launch_method(objgrid ? kmeth + 10 : kmeth, A, g, s);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(p->ev1, s));
-    if (A.big) {
+    if (custom_iv) {
+        if (two_pass) return fail(MET2_E_UNSUPPORTED, "MET2_TWO_PASS (A/B switch) does not go with non-default lambda-search intervals");
+        A.all_queued = 1;
+        HIPCHK(hipEventRecord(p->ev1, s));
+        rc = launch_method(kmeth, A, g, s, true);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(p->ev2, s));
+        p->timed2 = true;
+    } else {
+        rc = launch_method(objgrid ? kmeth + 10 : kmeth, A, g, s);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(p->ev1, s));
+    }
+    if (custom_iv) {
+    } else if (A.big) {
         // the spill-over kernel: the voxels the first kernel queued (their passive set outgrew the LDS capacity), same geometry, the solver with its
         // spill-over legs -- no re-sort, no second capacity; it finds an empty queue in most launches at one bin per lane
         rc = launch_method(kmeth, A, g, s, true);
@@ -2061,7 +2075,7 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
     }
     // FA index range errors (IndexError in the reference): the error word lands in the plan's pinned host word; the blocking entries
     // wait for it here, an enqueued fit leaves it to met2_plan_finish (errors of several enqueued fits accumulate: the kernel ORs)
-    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, 4 * sizeof(int), hipMemcpyDeviceToHost, s));      // the error word, the spill-over count (the queue's tail, head) and the sum of k
+    HIPCHK(hipMemcpyAsync(p->hErr, sb.err, 4 * sizeof(int), hipMemcpyDeviceToHost, s));      // the error word and the spill-over queue.s tail and head
     p->err_pending = true; p->err_stream = s;
     if (!sync) return MET2_OK;
     return met2_plan_finish(p, stream);
@@ -2252,13 +2266,6 @@ int met2_plan_last_spill_count(met2_plan *p, int64_t *count)
 {
     if (!p || !count) return fail(MET2_E_INVALID, "NULL argument");
     *count = p->last_spill;
-    return MET2_OK;
-}
-
-int met2_plan_last_mean_k(met2_plan *p, int64_t fitted, double *mean_k)
-{
-    if (!p || !mean_k) return fail(MET2_E_INVALID, "NULL argument");
-    *mean_k = fitted > 0 ? (double)p->last_ksum / (double)fitted : 0.0;
     return MET2_OK;
 }
 

@@ -322,12 +322,6 @@ class Met2Plan:
         check(lib().met2_plan_last_spill_count(self._h, C.byref(n)))
         return n.value
 
-    def last_mean_k(self, fitted_voxels):
-        """Mean passive-set size of the final solves of the most recent fit (fitted_voxels: how many of its voxels were fitted)."""
-        k = C.c_double(0.0)
-        check(lib().met2_plan_last_mean_k(self._h, int(fitted_voxels), C.byref(k)))
-        return k.value
-
     def gcv_form(self):
         """(low_rank, residual): whether GCV's trace is taken from the 17 x 17 form in the dictionary's low-rank basis on this plan."""
         lr, res = C.c_int32(0), C.c_double(0.0)
