@@ -643,12 +643,12 @@ __device__ __forceinline__ void nnls_iterate_plain(const WaveShared &S, const Ba
                                                    bool warm)
 {
     const int n = S.n, itmax = 3 * n;
-    int iter = 0, outer = 0;
-    if constexpr (BIG) if (st.k > S.kmax) { iterate_big<NB>(S, bd, st, lam, mrows, lane, warm, iter, outer); return; }      // (a warm start beyond the LDS capacity)
+    int iter = 0;
+    if constexpr (BIG) if (st.k > S.kmax) { int outer0 = 0; iterate_big<NB>(S, bd, st, lam, mrows, lane, warm, iter, outer0); return; }      // (a warm start beyond the LDS capacity)
     MET2_CYC_BEGIN(c_in0);
     if (warm && st.k > 0 && !nnls_inner<NB, NB, BS1>(S, st, iter, itmax, lane)) { st.itmax_hit |= 1; return; }
     MET2_CYC_END(2, c_in0);
-    for (; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
+    for (int outer = 0; outer <= itmax + 1; ++outer) {     // every pass runs >= 1 counted inner pass
         if (st.k >= n || st.k >= mrows) break;
         double w[NB];
         MET2_CYC_BEGIN(c_du);
