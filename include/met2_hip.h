@@ -58,8 +58,8 @@ enum met2_status {
     MET2_ST_NONFINITE = 4,     /* NaN/Inf in the voxel's echoes: outputs zero (reference: ValueError) */
     MET2_ST_CHOLFAIL = 8,      /* BayesReg: Cholesky of beta(B + lambda K) failed (reference: LinAlgError) */
     MET2_ST_BRENT_MAXFUN = 16, /* lambda search stopped on maxfun                                  */
-    MET2_ST_KOVERFLOW = 32     /* passive-set capacity of a pass exceeded: set only transiently -- the clean-up passes redo such
-                                  voxels at full capacity, so no voxel returned by met2_fit carries it */
+    MET2_ST_KOVERFLOW = 32     /* passive set outgrew the wave's LDS region: set only transiently -- the fit kernel queues such a voxel and
+                                  the spill-over kernel behind it solves it again, so no voxel returned by met2_fit carries it */
 };
 
 enum met2_error {
@@ -179,16 +179,19 @@ int met2_fit_enqueue_strided(met2_plan *plan, int32_t method, int64_t nvox, cons
                              double *reg, double *lam, double *maps, int32_t *status, void *stream);
 int met2_plan_finish(met2_plan *plan, void *stream);
 
-/* ---- host to host, one or several devices (ABI 5) ----------------------------------------
+/* ---- host to host, one or several devices (ABI 5; run-wise dealing since ABI 6) ----------
  * motor:349-373 + motor:427-472 for a voxel list that lives in HOST memory, as the reference's driver holds it (motor:167-182), from ONE
  * process: what a binding of the reference calls instead of its joblib loop over image rows (motor:427-441) -- numpy arrays in, numpy
  * arrays out, no device memory, stream or communicator on the caller's side.
  *   plans [n_plans]   1..64 distinct plans of one shape, configured alike (dictionary, penalty, options), each on the device of its
- *                     met2_options.device; several plans may share a device.  The voxel list is cut into blocks of `chunk` voxels
- *                     and block b is fitted by plan b mod n_plans (interleaved: tissue classes cluster in space and differ 10x in
- *                     iteration count).  Every plan is driven by its own host thread inside the call (one plan:
- *                     the calling thread) through three streams of its device: H2D of its block c + 1 | [FA estimation and] fit of
- *                     block c | D2H of block c - 1.  There is no exchange between devices.
+ *                     met2_options.device; several plans may share a device.  With several plans the voxel list is dealt in RUNS of
+ *                     4 096 voxels, run j -> plan j mod n_plans (interleaved: tissue classes cluster in space and differ 10x in
+ *                     iteration count; ABI 6 -- ABI 5 dealt whole blocks), and a plan's DMA block is `chunk`
+ *                     voxels of ITS runs, moved by pitched copies; rows with a pitch (echo_stride 1, voxel_stride > n_te) and general
+ *                     strides keep whole blocks, block b -> plan b mod n_plans.  Every plan is driven by its own host thread inside
+ *                     the call (one plan: the calling thread) through three streams of its device: H2D of its block c + 1 |
+ *                     [FA estimation and] fit of block c | D2H of block c - 1.  There is no exchange between devices.  The coarse plans
+ *                     of estimate_fa = 2 must be distinct, one per plan, and none of them in plans[].
  *   ALL array arguments are HOST pointers (data and fa_data may ALSO be device pointers: the volume as met2_tv_chambolle / met2_nesma /
  *   met2_smooth_separable left it -- then copied block by block device to device); arrays in pinned memory (hipHostMalloc,
  *   hipHostRegister) are copied from / to in place, pageable ones are staged through pinned block buffers by the plan's thread while its
@@ -211,8 +214,8 @@ int met2_plan_finish(met2_plan *plan, void *stream);
  *   fa_out [nvox]     out, may be NULL: the FA index every voxel was fitted with
  *   fa_gate [nvox]    out, may be NULL: 1.0 where the FA step's gate holds (fa_estimation.py:45: mask and a positive echo sum of what
  *                     the FA step sees), else 0.0 -- the driver reports a flip angle only there (motor:366-370)
- *   chunk             voxels per block; 0 = a quarter of a plan's share, in multiples of 4 096, at most 262 144 and (unless the share itself is
- *                     smaller) at least 65 536
+ *   chunk             voxels per DMA block (several plans: rounded up to whole runs of 4 096); 0 = a quarter of a plan's share, in multiples of
+ *                     4 096, at most 262 144 and (unless the share itself is smaller) at least 65 536
  *   plan_ms [n_plans] out, may be NULL: wall-clock ms every plan's thread spent in the call
  * Blocking.  Every voxel is solved on its own, so the outputs are bit for bit those of one met2_fit over the whole list, whatever
  * n_plans, chunk and the devices.  Returns the first failing plan's code (an FA index outside the dictionary: MET2_E_INVALID) after
