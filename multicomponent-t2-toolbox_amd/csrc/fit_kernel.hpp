@@ -37,6 +37,8 @@ struct SortBufs {
 // Internal kernel variant of MET2_GCV (not part of the ABI): the trace from the 17 x 17 form in the plan's low-rank basis (objectives.hpp,
 // gcv_basis_kernel); chosen by fit_impl when every flip angle's dictionary is of numerical rank <= 16.
 #define MET2_GCV_LR 6
+constexpr int LC_SAVE_DOUBLES = 18;      // per lane, two bins per lane: log norms 2, kept iterates 8, iterate 2, and 12 ints (kept sets 8, position + pivot order 4)
+
 struct FitArgs {
     int n, m, nfa, kmax, waves, chunk;
     int wave_doubles;   // LDS doubles owned by each wave (>= kmax(kmax+1)/2; n*n for GCV)
@@ -72,6 +74,10 @@ struct FitArgs {
     int chol_stride;
     double *big;                          // [grid * waves][big_stride]: every wave's spill-over slot for factor columns >= kmax (nnls_big.hpp), or NULL
     int big_stride;
+    double *lc_save;                      // L-curve at two bins per lane: [lc_cap][LC_SAVE_DOUBLES][64] sweep states of queued voxels (fit_voxel), or NULL
+    int spill_w2;                         // dev: the spill-over kernel's waves per workgroup (0: its own choice)
+    int *lc_at;                           // [lc_cap]: the grid point the sweep goes on from (nlam: the solve at the corner)
+    int lc_cap;
     double blam[MET2_BAYES_TABLE];        // the shared Brent abscissae lambda_j
 };
 
@@ -547,7 +553,7 @@ __device__ __forceinline__ void refine(const WaveShared &S, NnlsState<NB> &st, d
 // global slot (nnls_big.hpp).
 template <int METHOD, int NB, bool BIG>
 __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S, const Band<NB> &bd, const MetricLanes<NB> &ml, int64_t v, int fa,
-                                          int seed_k, bool have_seed, int lane, int wslot)
+                                          int seed_k, bool have_seed, int lane, int wslot, int qslot)
 {
     constexpr int ONE = (NB == 2) ? (((METHOD >= 10 ? METHOD - 10 : METHOD) <= MET2_LCURVE) ? 1 : MET2_ONE_REFAC) : 0;
     const int n = A.n, m = A.m;
@@ -561,6 +567,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
     nnls_reset<NB>(st);
     project<NB>(S, b, lane, st.h);
     double regv = 0.0, lamv = 0.0; int stat = MET2_ST_FITTED;
+    bool queued = false;                  // (the L-curve queues its voxel itself)
 
     if (METHOD == MET2_NNLS) {
         solve_cold<NB, ONE, BIG>(S, bd, st, 0.0, false, lane);
@@ -652,10 +659,33 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         constexpr int NS = 4;
         double le = 0.0, ln = 0.0, keep_x[NS][NB];
         int keep_p[NS][NB];
-        for (int i = 0; i < A.nlam; ++i) {
+        // A sweep whose set outgrows the LDS capacity (two bins per lane: ~5 % of the voxels, nearly all of them in the last grid points towards
+        // lambda = 0) is not solved again from its first grid point by the spill-over kernel: the voxel is queued HERE, the sweep's state (the log
+        // norms so far, the kept states, the iterate in hand) goes to the queue entry's record, and the spill-over instance goes on from the grid
+        // point that overflowed (LC_SAVE_DOUBLES per lane; entries beyond lc_cap start over).
+        int at = -1, i0 = 0;
+        bool from_saved = false;
+        if (BIG && NB == 2 && A.lc_save && qslot >= 0 && qslot < A.lc_cap) {
+            const double *rec = A.lc_save + (size_t)qslot * (LC_SAVE_DOUBLES * 64) + lane;
+            const int *reci = (const int *)(A.lc_save + (size_t)qslot * (LC_SAVE_DOUBLES * 64) + (2 + 5 * NB) * 64) + lane;
+            i0 = A.lc_at[qslot];
+            le = rec[0]; ln = rec[64];
+            int kk = 0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) { keep_x[q][bb] = rec[(2 + q * NB + bb) * 64]; keep_p[q][bb] = reci[(q * NB + bb) * 64]; }
+                st.x[bb] = rec[(2 + NS * NB + bb) * 64];
+                st.pos[bb] = reci[(NS * NB + bb) * 64]; st.ord[bb] = reci[(NS * NB + NB + bb) * 64];
+                st.P[bb] = ballot(st.pos[bb] >= 0); kk += __popcll(st.P[bb]);
+            }
+            st.k = kk;
+            from_saved = i0 >= A.nlam;
+        }
+        for (int i = i0; i < A.nlam; ++i) {
             double lam = A.lam_grid[i];
-            if (NB == 2 && (st.itmax_hit & 2)) break;       // capacity hit: solved again in the next pass
             solve_warm<NB, ONE, BIG>(S, bd, st, lam, true, lane);
+            if (!BIG && NB == 2 && (st.itmax_hit & 2)) { at = i; break; }      // capacity hit: the spill-over kernel goes on
             double sse = sse_of<NB>(S, st, b, lane);
             double sn = seminorm2<NB>(bd, st.x, n, lane);
             if (lane == i) { le = log(sse + 1e-200); ln = log(sn + 1e-200); }
@@ -666,10 +696,10 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
                     for (int bb = 0; bb < NB; ++bb) { keep_x[q][bb] = st.x[bb]; keep_p[q][bb] = (st.pos[bb] + 1) | (st.ord[bb] << 9); }
                 }
         }
-        if (!(NB == 2 && (st.itmax_hit & 2))) {
+        if (at < 0) {
         int corner = select_corner_dev(le, ln, A.nlam, lane);
         regv = lamv = A.lam_grid[corner];
-        {
+        if (!from_saved) {
             int best = -1, dist = A.nlam - 1 - corner;               // the state in hand belongs to the last grid point
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -690,6 +720,26 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
                 }
         }
         solve_warm<NB, ONE, BIG>(S, bd, st, regv, true, lane);
+        if (!BIG && NB == 2 && (st.itmax_hit & 2)) at = A.nlam;
+        }
+        if (!BIG && NB == 2 && at >= 0 && A.lc_save) {
+            int t = 0;
+            if (lane == 0) { t = atomicAdd(A.sb.err + 1, 1); A.sb.ovf[t] = (int)v; }
+            t = __builtin_amdgcn_readfirstlane(t);
+            queued = true;
+            if (t < A.lc_cap) {
+                double *rec = A.lc_save + (size_t)t * (LC_SAVE_DOUBLES * 64) + lane;
+                int *reci = (int *)(A.lc_save + (size_t)t * (LC_SAVE_DOUBLES * 64) + (2 + 5 * NB) * 64) + lane;
+                if (lane == 0) A.lc_at[t] = at;
+                rec[0] = le; rec[64] = ln;
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) { rec[(2 + q * NB + bb) * 64] = keep_x[q][bb]; reci[(q * NB + bb) * 64] = keep_p[q][bb]; }
+                    rec[(2 + NS * NB + bb) * 64] = st.x[bb];
+                    reci[(NS * NB + bb) * 64] = st.pos[bb]; reci[(NS * NB + NB + bb) * 64] = st.ord[bb];
+                }
+            }
         }
     } else if (METHOD == MET2_BAYESREG) {
         // bayesian_interpolation.py:84-105
@@ -790,7 +840,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         if (A.lam) A.lam[v] = lamv;
         if (A.status) A.status[v] = stat;
     }
-    return !BIG && (st.itmax_hit & 2) != 0;                     // the set outgrew the wave's LDS region (the outputs just written carry MET2_ST_KOVERFLOW): the caller queues the voxel for the spill-over kernel
+    return !BIG && !queued && (st.itmax_hit & 2) != 0;                     // the set outgrew the wave's LDS region (the outputs just written carry MET2_ST_KOVERFLOW): the caller queues the voxel for the spill-over kernel
 }
 
 // the wave's view of the plan: everything of WaveShared that does not depend on the flip angle
@@ -815,7 +865,7 @@ __device__ __forceinline__ void fit_shared_fa(const FitArgs &A, WaveShared &S, i
 // voxel -- every wave faulted on its second one (round 5: 3 020 queued voxels on 2 048 waves; 1 549 ran clean).  The arguments arrive in
 // vector registers and the plan's arguments through a private copy: everything wave-uniform is made scalar again (readfirstlane).
 template <int METHOD, int NB>
-__device__ __attribute__((noinline)) void fit_voxel_spill(const FitArgs *Ap, big_lds_dp sRl, int64_t v, int fa, int wslot)
+__device__ __attribute__((noinline)) void fit_voxel_spill(const FitArgs *Ap, big_lds_dp sRl, int64_t v, int fa, int wslot, int qslot)
 {
     const int lane = big_lane();
     double *sR = (double *)sRl;
@@ -827,7 +877,7 @@ __device__ __attribute__((noinline)) void fit_voxel_spill(const FitArgs *Ap, big
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(FitArgs) / 4); ++i) dst[i] = big_rfl(src[i]);
     }
-    v = (int64_t)big_rfl((u64)v); fa = big_rfl(fa); wslot = big_rfl(wslot);
+    v = (int64_t)big_rfl((u64)v); fa = big_rfl(fa); wslot = big_rfl(wslot); qslot = big_rfl(qslot);
     WaveShared S;
     fit_shared(A, S, sR, wslot);
     fit_shared_fa<METHOD>(A, S, fa);
@@ -837,7 +887,7 @@ __device__ __attribute__((noinline)) void fit_voxel_spill(const FitArgs *Ap, big
     metric_lanes<NB>(ml, A.t2s, A.n, A.cut_m, A.cut_ie, lane);
     const int seed_k = (MET2_SEED && A.seed) ? ((const SeedRec *)A.seed)[fa].k : 0;
     const bool have_seed = seed_k > 0 && seed_k <= A.kmax;
-    (void)fit_voxel<METHOD, NB, true>(A, S, bd, ml, v, fa, seed_k, have_seed, lane, wslot);
+    (void)fit_voxel<METHOD, NB, true>(A, S, bd, ml, v, fa, seed_k, have_seed, lane, wslot, qslot);
 }
 
 // SECOND = false: the fit kernel proper.  Every wave pulls voxels from the FA-sorted queue; a voxel whose passive set outgrows the wave's LDS region
@@ -900,7 +950,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
             MET2_STAT(4, slot);
             const int64_t v = A.sb.perm[first + slot];
 
-            if (fit_voxel<METHOD, NB, false>(A, S, bd, ml, v, fa, seed_k, have_seed, lane, wslot) && A.big) {
+            if (fit_voxel<METHOD, NB, false>(A, S, bd, ml, v, fa, seed_k, have_seed, lane, wslot, -1) && A.big) {
                 // the set outgrew the wave's LDS region: the voxel goes to the spill-over queue
                 if (lane == 0) A.sb.ovf[atomicAdd(A.sb.err + 1, 1)] = (int)v;
             }
@@ -920,6 +970,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
         const int total = A.waves * A.wave_doubles, wgs = (int)gridDim.x;
         int w2 = A.waves;
         while (w2 > 1 && (int64_t)(w2 - 1) * wgs >= ntail) --w2;
+        if (A.spill_w2 > 0 && A.spill_w2 <= A.waves) w2 = A.spill_w2;
         const int per = (total / w2) & ~1;
         int k2 = A.kmax;
         while (k2 < n && col_base(k2 + 1) <= per) ++k2;
@@ -933,7 +984,7 @@ __global__ __launch_bounds__(64 * method_max_waves(METHOD, NB)) void fit_kernel(
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= ntail) break;
         const int64_t v = queue[i];
-        fit_voxel_spill<METHOD, NB>(&Ac, (big_lds_dp)sR, v, A.sb.key[v], wslot);
+        fit_voxel_spill<METHOD, NB>(&Ac, (big_lds_dp)sR, v, A.sb.key[v], wslot, A.all_queued ? -1 : i);
     }
     }
     }

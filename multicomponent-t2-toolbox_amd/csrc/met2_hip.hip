@@ -1028,6 +1028,7 @@ struct met2_plan {
     double gcv_res = 0.0;                                 // the largest of dAqRes
     bool gcv_lr = false;                                  // every flip angle's dictionary is of numerical rank <= 16: the GCV trace takes the 17 x 17 form
     double *dChol = nullptr; int64_t cap_chol = 0;        // BayesReg at two bins per lane: one packed factor per resident wave (chol_lean), grown on demand
+    double *dLcSave = nullptr; int64_t cap_lc = 0;        // L-curve at two bins per lane: the sweep states of queued voxels (fit_kernel.hpp: FitArgs::lc_save) and, behind them, lc_at
     double *dBig = nullptr; int64_t cap_big = 0;          // the waves' spill-over slots: factor columns beyond the LDS capacity (nnls_big.hpp), grown on demand
     int last_spill = 0;                                   // voxels of the last finished fit(s) that used them
     double blam[MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1];
@@ -1619,7 +1620,7 @@ int met2_plan_destroy(met2_plan *p)
     if (!p) return MET2_OK;
     met2::host_release(p);           // what met2_fit_host keeps with the plan (met2_host.hip)
     DevGuard dev_guard_(p->opt.device);
-    void *bufs[] = {p->dQt, p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dOvf, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol, p->dBig};
+    void *bufs[] = {p->dQt, p->dAq, p->dAqRes, p->dD, p->dB, p->dDt, p->dKband, p->dLband, p->dKd, p->dLam, p->dT2, p->dKey, p->dPerm, p->dOvf, p->dSmall, p->dStatus, p->dSeed, p->dBtab, p->dH, p->dChol, p->dBig, p->dLcSave};
     for (void *b : bufs) (void)hipFree(b);
     if (p->hErr) (void)hipHostFree(p->hErr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1970,6 +1971,19 @@ static int fit_impl(met2_plan *p, int32_t method, int64_t nvox, const double *da
             p->cap_big = need;
         }
         A.big = p->dBig; A.big_stride = stride;
+    }
+    A.lc_save = nullptr; A.lc_at = nullptr; A.lc_cap = 0;
+    A.spill_w2 = getenv("MET2_SPILL_W2") ? atoi(getenv("MET2_SPILL_W2")) : 0;      // test switch (A/B)
+    if (A.big && method == MET2_LCURVE && g.nb == 2 && !objgrid && !getenv("MET2_LC_RESTART")) {
+        // records for a sixteenth of the voxels (5 % of them overflow on measured spectra), between 4 096 and 262 144 (2.4 GB): entries beyond start over
+        const int64_t cap = std::min<int64_t>(nvox, std::min<int64_t>(262144, std::max<int64_t>(4096, nvox / 16)));
+        const int64_t need = cap * (LC_SAVE_DOUBLES * 64) + (cap + 1) / 2;
+        if (p->cap_lc < need) {
+            if (p->dLcSave) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(p->dLcSave)); p->dLcSave = nullptr; p->cap_lc = 0; }
+            HIPCHK(hipMalloc(&p->dLcSave, sizeof(double) * (size_t)need));
+            p->cap_lc = need;
+        }
+        A.lc_save = p->dLcSave; A.lc_at = (int *)(p->dLcSave + cap * (LC_SAVE_DOUBLES * 64)); A.lc_cap = (int)cap;
     }
     const bool ladder = kfast && !A.big;
     for (int j = 0; j < (MET2_BAYES_TABLE > 0 ? MET2_BAYES_TABLE : 1); ++j) A.blam[j] = p->blam[j];

@@ -252,3 +252,34 @@ def test_fit_sharded_over_a_two_rank_rccl_group(tmp_path):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
                         str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "RCCL2_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+@gpu
+def test_lcurve_spill_over_goes_on_from_the_saved_sweep_state():
+    """L-curve at two bins per lane: a voxel whose set outgrows the LDS capacity is queued with its sweep's state (log norms so far, kept states,
+    the iterate in hand: fit_kernel.hpp, FitArgs::lc_save) and the spill-over kernel goes on from the grid point that overflowed.  Against the
+    same library starting such voxels over (MET2_LC_RESTART, read at every fit): the same corner for every voxel, spectra equal to rounding
+    (the saved iterate is re-factorised where the uninterrupted sweep carried its factor along)."""
+    import torch
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2, nvox = 48, 120, 8192
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plan = pkg.Met2Plan(nte, nt2, 1)
+    plan.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty("L1", T2s)
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=20260110, device="cuda")
+    a = plan.fit("L_curve", data, want_lambda=True)
+    n_spill = plan.last_spill_count()
+    assert n_spill > 100, n_spill                     # ~5 % of the voxels at this shape
+    os.environ["MET2_LC_RESTART"] = "1"
+    try:
+        b = plan.fit("L_curve", data, want_lambda=True)
+        assert plan.last_spill_count() == n_spill
+    finally:
+        os.environ.pop("MET2_LC_RESTART", None)
+    assert torch.equal(a["status"], b["status"]) and int((a["status"] > 0).sum()) == nvox
+    assert torch.equal(a["lam"], b["lam"])
+    fa_, fb_ = a["fsol"].cpu().numpy(), b["fsol"].cpu().numpy()
+    rel = np.abs(fa_ - fb_).max(axis=1) / np.abs(fb_).max(axis=1)
+    print("MEASURED L-curve resume vs restart: %d queued, max rel diff %.2e, differing voxels %d" % (n_spill, rel.max(), (rel > 0).sum()))
+    assert rel.max() < 1e-9
