@@ -81,11 +81,37 @@ struct FitArgs {
     double blam[MET2_BAYES_TABLE];        // the shared Brent abscissae lambda_j
 };
 
+// The searches below run redundantly on all lanes, on wave-uniform doubles that the VALU computes into vector registers: eleven of them live across
+// every objective evaluation (a whole NNLS solve), 22 VGPRs of the solver's budget.  uni() moves such a value into a scalar register pair
+// (v_readfirstlane x 2); what the scalar file cannot hold the compiler keeps in the lanes of one VGPR (v_writelane), 64 scalars per register.
+// Per kernel (bit of MET2_UNI_MASK: X2 1 | 2, GCV 4 | 8, BayesReg 16 | 32 at one | two bins per lane): measured, the scalar copies cost the
+// two-bins-per-lane X2 and GCV kernels more in lane reads and writes than their (L2-resident) spills did.
+#ifndef MET2_UNI_MASK
+#define MET2_UNI_MASK 37
+#endif
+constexpr bool uni_brent(int method, int nb)
+{
+    const int base = method >= 10 ? method - 10 : method;
+    const int bit = base == MET2_X2 ? 0 : ((base == MET2_GCV || base == MET2_GCV_LR) ? 2 : (base == MET2_BAYESREG ? 4 : -1));
+    return bit >= 0 && ((MET2_UNI_MASK >> (bit + (nb == 2 ? 1 : 0))) & 1);
+}
+template <bool PIN>
+__device__ __forceinline__ double uni(double v)
+{
+    if constexpr (PIN) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    } else return v;
+}
+#define MET2_UNI_PIN() do { a = uni<PIN>(a); b = uni<PIN>(b); fulc = uni<PIN>(fulc); nfc = uni<PIN>(nfc); xf = uni<PIN>(xf); rat = uni<PIN>(rat); e = uni<PIN>(e); \
+                            x = uni<PIN>(x); fx = uni<PIN>(fx); ffulc = uni<PIN>(ffulc); fnfc = uni<PIN>(fnfc); } while (0)
+
 // SciPy's bounded Brent (scipy.optimize.fminbound, called at algorithms.py:219,280 and
 // bayesian_interpolation.py:101), restated; executed redundantly by all lanes on uniform values.
 // on_best() is called whenever the abscissa just evaluated becomes Brent's best point xf (the value fminbound returns): callers
 // keep the solver state of that evaluation and skip the solve scipy's callers repeat at the returned lambda.
-template <class F, class G>
+template <bool PIN, class F, class G>
 __device__ __forceinline__ double fminbound_dev(F &&fn, G &&on_best, double x1, double x2, double xatol, int maxfun, int &flag)
 {
     const double sqrt_eps = sqrt(2.2e-16);
@@ -133,6 +159,7 @@ __device__ __forceinline__ double fminbound_dev(F &&fn, G &&on_best, double x1, 
         double si = (double)((rat > 0.0) - (rat < 0.0) + (rat == 0.0));
         double ar = fabs(rat);
         x = xf + si * (ar > tol1 ? ar : tol1);
+        MET2_UNI_PIN();
         fu = fn(x);
         num++;
         if (fu <= fx) {
@@ -179,7 +206,7 @@ __device__ __forceinline__ double fminbound_dev(F &&fn, G &&on_best, double x1, 
 // `fu <= fx`, `fu <= fnfc`, `fu <= ffulc` -- is closer than that noise can decide, the values involved are evaluated again, refined
 // (each retained point at most once), and the decision is taken on those.  The re-evaluations are not counted in `num`: the sequence
 // of abscissae is scipy's.  on_best() follows xf as before (also when xf's value has just been refined: the state in hand is xf's).
-template <class F, class G>
+template <bool PIN, class F, class G>
 __device__ __forceinline__ double fminbound_tie_dev(F &&fn, G &&on_best, double x1, double x2, double xatol, int maxfun, int &flag, int &nref)
 {
     const double sqrt_eps = sqrt(2.2e-16);
@@ -248,6 +275,7 @@ __device__ __forceinline__ double fminbound_tie_dev(F &&fn, G &&on_best, double 
         double si = (double)((rat > 0.0) - (rat < 0.0) + (rat == 0.0));
         double ar = fabs(rat);
         x = xf + si * (ar > tol1 ? ar : tol1);
+        MET2_UNI_PIN();
         fu = fn(x, false);
         bool ru = false;
         num++;
@@ -578,8 +606,9 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
     } else if (METHOD == MET2_X2) {
         // algorithms.py:211-233
         solve_cold<NB, ONE, BIG>(S, bd, st, 0.0, false, lane);
-        const double SSE = sse_of<NB>(S, st, b, lane);
-        const double target = A.x2_factor * SSE;
+        constexpr bool PIN = uni_brent(METHOD, NB);
+        const double SSE = uni<PIN>(sse_of<NB>(S, st, b, lane));
+        const double target = uni<PIN>(A.x2_factor * SSE);
         int flag;
         double last_x = -1.0, last_sse = 0.0;
         if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);     // start of the first Brent point
@@ -592,11 +621,11 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
 #endif
 #if MET2_TIE_GUARD
         int nref = 0;
-        double lam = fminbound_tie_dev([&](double x, bool refined) {
+        double lam = fminbound_tie_dev<uni_brent(METHOD, NB)>([&](double x, bool refined) {
             if (NB == 2 && (st.itmax_hit & 2)) return 0.0;
             if (!(refined && x == last_x)) solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
             if (refined) refine<NB, BIG>(S, st, x, b, lane);
-            const double SSEr = sse_of<NB>(S, st, b, lane);
+            const double SSEr = uni<PIN>(sse_of<NB>(S, st, b, lane));
             last_x = x; last_sse = SSEr;
             return fabs(SSEr - target) / SSE;
         }, [&]() {
@@ -606,7 +635,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         }, BIG ? A.lam_lo : 0.0, BIG ? A.lam_hi : 10.0, A.xtol, A.maxfun, flag, nref);
         if (MET2_TIE_GUARD == 2 && nref) stat |= 64 | (nref & 0x1f00);
 #else
-        double lam = fminbound_dev([&](double x) {
+        double lam = fminbound_dev<uni_brent(METHOD, NB)>([&](double x) {
 #ifdef MET2_CYCSTATS
             unsigned long long snap[8];
             for (int q_ = 0; q_ < 8; ++q_) snap[q_] = st.cyc[q_];
@@ -620,7 +649,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
                                                             // where 5-10 % of the voxels do; at one bin per lane ~1 % do and the test cost
                                                             // the X2 kernel two more spilled registers)
             solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
-            double SSEr = sse_of<NB>(S, st, b, lane);
+            double SSEr = uni<PIN>(sse_of<NB>(S, st, b, lane));
 #ifdef MET2_CYCSTATS
             if (lane == 0) {
                 const int e_ = evi < 39 ? evi : 39;
@@ -753,7 +782,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         int flag, ev = 0;
         if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
         double *cholG = (NB == 2 && A.chol) ? A.chol + (size_t)wslot * (size_t)A.chol_stride : nullptr;
-        double lam = fminbound_dev([&](double x) {
+        double lam = fminbound_dev<uni_brent(METHOD, NB)>([&](double x) {
             if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
             solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
             BayesTable tab{nullptr, 0.0};
@@ -778,7 +807,7 @@ __device__ __forceinline__ bool fit_voxel(const FitArgs &A, const WaveShared &S,
         int flag, overflow = 0;
         GcvCache<NB> gc; gc.valid = 0; gc.next = 0;
         if (have_seed) seed_load<NB>(st, A.seed, seed_k, fa, lane);
-        double lam = fminbound_dev([&](double x) {
+        double lam = fminbound_dev<uni_brent(METHOD, NB)>([&](double x) {
             if (NB == 2 && (st.itmax_hit & 2)) return 0.0;  // capacity hit: solved again in the next pass
             solve_warm<NB, ONE, BIG>(S, bd, st, x, true, lane);
             return gcv_objective<NB, METHOD == MET2_GCV_LR>(S, bd, st, x, b, lane, overflow, gc);

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(128) void fa_spline_kernel(SplineArgs A)
         s[i] = t;
     }
     int flag;
-    const double xs = fminbound_dev([&](double x) { return spline_eval_dev(n, sx, y, s, x); }, []() {}, 90.0, 180.0, 1e-5, 500, flag);
+    const double xs = fminbound_dev<false>([&](double x) { return spline_eval_dev(n, sx, y, s, x); }, []() {}, 90.0, 180.0, 1e-5, 500, flag);
     int best = 0; double dbest = fabs(A.alpha_hr[0] - xs);            // np.argmin(|alpha - x|): first minimum
     for (int a = 1; a < A.nhr; ++a) { double d = fabs(A.alpha_hr[a] - xs); if (d < dbest) { dbest = d; best = a; } }
     A.fa_index[v] = (double)best;
