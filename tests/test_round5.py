@@ -283,3 +283,32 @@ def test_lcurve_spill_over_goes_on_from_the_saved_sweep_state():
     rel = np.abs(fa_ - fb_).max(axis=1) / np.abs(fb_).max(axis=1)
     print("MEASURED L-curve resume vs restart: %d queued, max rel diff %.2e, differing voxels %d" % (n_spill, rel.max(), (rel > 0).sum()))
     assert rel.max() < 1e-9
+
+
+@gpu
+def test_lcurve_saved_sweep_states_through_the_host_entry():
+    """The L-curve's sweep-state records (FitArgs::lc_save) are sized per fit: through met2_fit_host a plan fits block after block (different sizes, the
+    last one ragged) and two plans hold records of their own.  48 x 120, L1: bit-equal to one plan.fit over the whole list, and voxels were queued."""
+    import torch
+    pkg = importlib.import_module(PKG)
+    host = importlib.import_module(PKG + ".host")
+    synth = importlib.import_module(PKG + ".synth")
+    nte, nt2, nvox = 48, 120, 3 * 4096 + 777
+    T2s = synth.t2_grid(nt2); T1s = 1000.0 * np.ones(nt2)
+    plans = []
+    for _ in range(2):
+        p = pkg.Met2Plan(nte, nt2, 1)
+        p.build_dictionary_epg(T2s, T1s, 10.0, np.array([150.0]), 3000.0).set_penalty("L1", T2s)
+        plans.append(p)
+    data, _, _ = synth.make_voxels(nvox, nte=nte, seed=20260111, device="cuda")
+    ref = plans[0].fit("L_curve", data, want_lambda=True)
+    assert plans[0].last_spill_count() > 50
+    d = data.cpu().numpy()
+    for pl, chunk in ((plans[:1], 4096), (plans, 4096), (plans, 0)):
+        got = host.fit_host(pl, "L_curve", d, want_lambda=True, chunk=chunk)
+        for k in ("fsol", "sig", "reg", "lam", "maps", "status"):
+            r = ref[k]
+            r = r.cpu().numpy() if hasattr(r, "cpu") else r
+            assert np.array_equal(np.asarray(got[k]).reshape(r.shape), r), (len(pl), chunk, k)
+    for p in plans:
+        p.close()
