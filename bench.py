@@ -442,6 +442,15 @@ def host_driver_main(args):
                      "note": "algorithmic bytes of the fitted voxels over the host-to-host wall time of the whole call (all devices); the kernel's own "
                              "roofline is in the default driver's line"},
     }
+    # the binding roofline, as far as this driver can see it: k measured on the outputs, the dominant kernel's registers; the counter-derived rate
+    # belongs to one launch on resident data and is in the default driver's line
+    mean_k = float((res["fsol"] > 0).sum()) / max(fitted, 1)
+    info = plans[0].launch_info(method)
+    line["roofline_fp64"] = {"bound": "fp64 vector issue", "peak": FP64_VECTOR_PEAK_TFLOPS * N, "unit": "TFLOP/s", "achieved": None, "frac": None,
+                             "waves_per_simd_launched": info["block"] // 64 / 4.0, "mean_final_passive_set_k": mean_k,
+                             "live_lane_frac_position_phases": mean_k / 64.0,
+                             "registers": kernel_resources(method, 2 if nt2 > 64 else 1) or "no profiles/*_kernel_resource_usage.csv for these sources",
+                             "note": "achieved (issued fp64 FLOP/s of one launch on device-resident data) is in the default driver's line: python bench.py"}
     print(json.dumps(line), flush=True)
     for pl in plans:
         pl.close()
